@@ -1,0 +1,101 @@
+/* scenesplat_hip.h -- C-ABI of libscenesplat_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the native ops behind SceneSplat's PTv3 hot path.  Every entry point
+ * takes raw DEVICE pointers, explicit sizes and a HIP stream, returns an int status
+ * (SS_OK = 0), allocates nothing, keeps no global state and is re-entrant per stream; the
+ * caller owns all memory (outputs and workspaces; sizes from the *_workspace_bytes queries).
+ * No torch types appear here.  Reference interfaces replaced (paths under /root/reference):
+ *
+ *   ss_serialize_encode / ss_argsort_i64      pointcept/models/utils/structure.py:81-92
+ *                                             (encode(): utils/serialization/default.py:8-24)
+ *   ss_pool_partition / ss_pool_level_attrs   point_transformer_v3m1_base.py:384-398,422-427
+ *   ss_window_index                           point_transformer_v3m1_base.py:114-170,184-185
+ *   ss_subm_rulebook + ss_subm_conv_*         spconv.SubMConv3d (ptv3:278-284,499-506; structure.py:131-138)
+ *   ss_segment_reduce / ss_segment_bcast      torch_scatter.segment_csr (ptv3:416-421)
+ *   ss_gather_rows / ss_scatter_rows / ss_gather_add_rows   feat[idx] row indexing (ptv3:188,216,417,478)
+ *   ss_window_attn_fwd / ss_window_attn_bwd   flash_attn.flash_attn_varlen_qkvpacked_func (ptv3:208-214)
+ *   ss_lang_head_*                            models/default.py:98-109, losses/misc.py:254-295,355-388
+ *   ss_knn_query ... ss_bfs_cluster           libs/pointops/src/pointops_api.cpp:15-31,
+ *                                             libs/pointops2/src/pointops_api.cpp:17-44,
+ *                                             libs/pointgroup_ops/src/bfs_cluster.cpp:140-145
+ */
+#ifndef SCENESPLAT_HIP_H
+#define SCENESPLAT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct ihipStream_t;
+typedef struct ihipStream_t* ss_stream_t; /* == hipStream_t */
+
+#define SS_MAX_ORDERS 8
+enum { SS_ORDER_Z = 0, SS_ORDER_Z_TRANS = 1, SS_ORDER_HILBERT = 2, SS_ORDER_HILBERT_TRANS = 3 };
+enum { SS_DTYPE_F32 = 0, SS_DTYPE_BF16 = 1 };
+enum { SS_ATTN_SIMT = 0, SS_ATTN_MFMA = 1 };
+
+int ss_version(void);
+
+/* ---- serialization ------------------------------------------------------------------- */
+/* codes[k][i] = (batch[i] << 3*depth) | key_{orders[k]}(grid_coord[i]); grid_coord (n,3) int32 >= 0 */
+int ss_serialize_encode(const int32_t* grid_coord, const int32_t* batch, int64_t n, int depth, const int* orders,
+                        int num_orders, int64_t* codes, ss_stream_t stream);
+int ss_offsets_to_batch(const int32_t* offsets, int num_batches, int64_t n, int32_t* batch, ss_stream_t stream);
+int ss_count_duplicates(const int64_t* sorted_keys, int64_t n, int32_t* count, ss_stream_t stream);
+int ss_grid_coord_max(const int32_t* grid_coord, int64_t n, int32_t* out_max, ss_stream_t stream);
+/* stable argsort of num_segments independent rows of n non-negative int64 keys (low key_bits
+ * significant).  order_out (num_segments,n) int32; inverse_out / sorted_keys_out optional. */
+size_t ss_argsort_workspace_bytes(int64_t n, int num_segments);
+int ss_argsort_i64(const int64_t* keys, int num_segments, int64_t n, int key_bits, int32_t* order_out,
+                   int32_t* inverse_out, int64_t* sorted_keys_out, void* workspace, size_t workspace_bytes,
+                   ss_stream_t stream);
+
+/* ---- grid pooling structure ---------------------------------------------------------- */
+size_t ss_pool_partition_workspace_bytes(int64_t n);
+/* cluster (n), idx_ptr (n+1 capacity), head (n capacity), n_out (1): clusters are the runs of
+ * equal (code0 >> shift_bits) along order0; indices of segment_csr == order0. */
+int ss_pool_partition(const int64_t* code0, const int32_t* order0, int64_t n, int shift_bits, int32_t* cluster,
+                      int32_t* idx_ptr, int32_t* head, int32_t* n_out, void* workspace, size_t workspace_bytes,
+                      ss_stream_t stream);
+int ss_pool_level_attrs(const int32_t* head, int64_t n_out, int64_t n_in, const int32_t* grid_coord,
+                        const int32_t* batch, const int64_t* codes, int num_orders, int pool_depth,
+                        int32_t* grid_coord_out, int32_t* batch_out, int64_t* codes_out, ss_stream_t stream);
+int ss_batch_offsets(const int32_t* batch, const int32_t* perm, int64_t n, int num_batches, int32_t* offsets,
+                     ss_stream_t stream);
+
+/* ---- attention windows ---------------------------------------------------------------- */
+/* offsets / offsets_pad: (num_batches+1) int32 exclusive prefix sums (leading 0). */
+int ss_window_index(const int32_t* order, const int32_t* offsets, const int32_t* offsets_pad, int num_batches,
+                    int patch_size, int64_t n_pad, int32_t* gidx, int32_t* sidx, ss_stream_t stream);
+/* qkv (n,3C); out (n,C); lse (n_pad,H) f32; win_start (num_windows+1) int32 = cu_seqlens */
+int ss_window_attn_fwd(const void* qkv, const int32_t* gidx, const int32_t* sidx, const int32_t* win_start,
+                       int num_windows, int max_window, int64_t n, int64_t n_pad, int channels, int num_heads,
+                       float scale, int dtype, int impl, void* out, float* lse, ss_stream_t stream);
+size_t ss_window_attn_bwd_workspace_bytes(int64_t n, int64_t n_pad, int channels, int num_heads, int dtype);
+int ss_window_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* gidx,
+                       const int32_t* sidx, const int32_t* win_start, int num_windows, int max_window, int64_t n,
+                       int64_t n_pad, int channels, int num_heads, float scale, int dtype, int impl, void* dqkv,
+                       void* workspace, size_t workspace_bytes, ss_stream_t stream);
+
+/* ---- submanifold convolution ------------------------------------------------------------ */
+/* nbr (k^3, n) int32 (tap-major), -1 = no site; zkeys_sorted/zorder: z (or z-trans, swap_xy=1) codes sorted */
+int ss_subm_rulebook(const int32_t* grid_coord, const int32_t* batch, int64_t n, int depth,
+                     const int64_t* zkeys_sorted, const int32_t* zorder, int swap_xy, int kernel_size, int32_t* nbr,
+                     ss_stream_t stream);
+
+/* ---- row movement ------------------------------------------------------------------------ */
+int ss_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_dst, int64_t row_bytes, ss_stream_t stream);
+int ss_scatter_rows(const void* src, const int32_t* idx, void* dst, int64_t n_src, int64_t row_bytes, ss_stream_t stream);
+int ss_gather_add_rows(const void* a, const void* b, const int32_t* idx, void* dst, int64_t n, int channels, int dtype,
+                       ss_stream_t stream);
+int ss_segment_reduce(const void* src, const int32_t* indices, const int32_t* idx_ptr, void* out, int64_t n_seg,
+                      int channels, int dtype, int mean, ss_stream_t stream);
+int ss_segment_bcast(const void* dout, const int32_t* cluster, const int32_t* idx_ptr, void* dsrc, int64_t n,
+                     int channels, int dtype, int mean, ss_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCENESPLAT_HIP_H */

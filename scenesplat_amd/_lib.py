@@ -1,0 +1,72 @@
+"""ctypes binding of libscenesplat_hip.so (the C-ABI declared in include/scenesplat_hip.h).
+
+Loading fails loudly: there is no CPU fallback behind these symbols."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libscenesplat_hip.so")
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_f = ctypes.c_float
+c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/scenesplat_hip.h declares
+PROTOTYPES = {
+    "ss_version": (c_i, []),
+    "ss_serialize_encode": (c_i, [c_p, c_p, c_i64, c_i, ctypes.POINTER(c_i), c_i, c_p, c_p]),
+    "ss_offsets_to_batch": (c_i, [c_p, c_i, c_i64, c_p, c_p]),
+    "ss_count_duplicates": (c_i, [c_p, c_i64, c_p, c_p]),
+    "ss_grid_coord_max": (c_i, [c_p, c_i64, c_p, c_p]),
+    "ss_argsort_workspace_bytes": (c_sz, [c_i64, c_i]),
+    "ss_argsort_i64": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "ss_pool_partition_workspace_bytes": (c_sz, [c_i64]),
+    "ss_pool_partition": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]),
+    "ss_pool_level_attrs": (c_i, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "ss_batch_offsets": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p]),
+    "ss_window_index": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i64, c_p, c_p, c_p]),
+    "ss_window_attn_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i, c_f, c_i, c_i, c_p, c_p, c_p]),
+    "ss_window_attn_bwd_workspace_bytes": (c_sz, [c_i64, c_i64, c_i, c_i, c_i]),
+    "ss_window_attn_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i, c_f, c_i, c_i,
+                                 c_p, c_p, c_sz, c_p]),
+    "ss_subm_rulebook": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
+    "ss_gather_rows": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_p]),
+    "ss_scatter_rows": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_p]),
+    "ss_gather_add_rows": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p]),
+    "ss_segment_reduce": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
+    "ss_segment_bcast": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Return the loaded library (cached).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m scenesplat_amd.build` "
+            "(hipcc --offload-arch=gfx950). scenesplat_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_STATUS = {1: "bad argument", 2: "kernel launch failed", 3: "workspace too small"}
+
+
+def check(rc, name):
+    if rc != 0:
+        raise NativeError(f"{name} failed: status {rc} ({_STATUS.get(rc, 'unknown')})")

@@ -1,0 +1,11 @@
+#pragma once
+#include "common.h"
+int ss_attn_fwd_simt(const void* qkv, const int32_t* gidx, const int32_t* sidx, const int32_t* win_start, int W,
+                     void* out, float* lse, int C, int H, float scale, int dtype, hipStream_t st);
+int ss_attn_delta(const void* out, const void* dout, const int32_t* sidx, float* delta, int64_t n_pad, int C, int H,
+                  int dtype, hipStream_t st);
+int ss_attn_fix_borrowed(const int32_t* gidx, const int32_t* sidx, int64_t n_pad, const void* extra, void* dqkv, int C,
+                         int dtype, hipStream_t st);
+int ss_attn_bwd_simt(const void* qkv, const void* dout, const float* lse, const float* delta, const int32_t* gidx,
+                     const int32_t* sidx, const int32_t* win_start, int W, void* dqkv, void* extra, int C, int H,
+                     float scale, int dtype, hipStream_t st);

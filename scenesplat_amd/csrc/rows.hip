@@ -1,0 +1,148 @@
+// Row movement kernels (HBM-bound): indexed gather / scatter of feature rows, the serialized
+// grid-pool segment reduce and its broadcast backward, and the unpool gather-add.
+// Replaces, on the PTv3 path, feat[indices] / feat[inverse] indexing (ptv3:188,216,417,478) and
+// torch_scatter.segment_csr (ptv3:416-421).  Every source row and index is read once and every
+// destination row written once, 16 bytes per lane where the row width allows.
+#include "common.h"
+#include "../../include/scenesplat_hip.h"
+
+template <typename V>
+__global__ void k_gather_rows(const V* __restrict__ src, const int32_t* __restrict__ idx, V* __restrict__ dst,
+                              int64_t n_dst, int chunks) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_dst * chunks) return;
+  int64_t r = gid / chunks; int c = (int)(gid - r * chunks);
+  int32_t s = idx[r];
+  V v; 
+  if (s >= 0) v = src[(int64_t)s * chunks + c]; else v = V{};
+  dst[gid] = v;
+}
+template <typename V>
+__global__ void k_scatter_rows(const V* __restrict__ src, const int32_t* __restrict__ idx, V* __restrict__ dst,
+                               int64_t n_src, int chunks) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_src * chunks) return;
+  int64_t r = gid / chunks; int c = (int)(gid - r * chunks);
+  int32_t d = idx[r];
+  if (d >= 0) dst[(int64_t)d * chunks + c] = src[gid];
+}
+
+extern "C" int ss_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_dst, int64_t row_bytes,
+                              hipStream_t stream) {
+  if (n_dst < 0 || row_bytes <= 0 || (row_bytes & 1)) return SS_ERR_ARG;
+  if (n_dst == 0) return SS_OK;
+  if ((row_bytes & 15) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    int chunks = (int)(row_bytes >> 4);
+    SS_LAUNCH(k_gather_rows<uint4>, dim3(ss_div_up(n_dst * chunks, 256)), dim3(256), 0, stream,
+                       (const uint4*)src, idx, (uint4*)dst, n_dst, chunks);
+  } else if ((row_bytes & 3) == 0) {
+    int chunks = (int)(row_bytes >> 2);
+    SS_LAUNCH(k_gather_rows<uint32_t>, dim3(ss_div_up(n_dst * chunks, 256)), dim3(256), 0, stream,
+                       (const uint32_t*)src, idx, (uint32_t*)dst, n_dst, chunks);
+  } else {
+    int chunks = (int)(row_bytes >> 1);
+    SS_LAUNCH(k_gather_rows<uint16_t>, dim3(ss_div_up(n_dst * chunks, 256)), dim3(256), 0, stream,
+                       (const uint16_t*)src, idx, (uint16_t*)dst, n_dst, chunks);
+  }
+  SS_CHECK_LAUNCH();
+  return SS_OK;
+}
+extern "C" int ss_scatter_rows(const void* src, const int32_t* idx, void* dst, int64_t n_src, int64_t row_bytes,
+                               hipStream_t stream) {
+  if (n_src < 0 || row_bytes <= 0 || (row_bytes & 1)) return SS_ERR_ARG;
+  if (n_src == 0) return SS_OK;
+  if ((row_bytes & 15) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    int chunks = (int)(row_bytes >> 4);
+    SS_LAUNCH(k_scatter_rows<uint4>, dim3(ss_div_up(n_src * chunks, 256)), dim3(256), 0, stream,
+                       (const uint4*)src, idx, (uint4*)dst, n_src, chunks);
+  } else if ((row_bytes & 3) == 0) {
+    int chunks = (int)(row_bytes >> 2);
+    SS_LAUNCH(k_scatter_rows<uint32_t>, dim3(ss_div_up(n_src * chunks, 256)), dim3(256), 0, stream,
+                       (const uint32_t*)src, idx, (uint32_t*)dst, n_src, chunks);
+  } else {
+    int chunks = (int)(row_bytes >> 1);
+    SS_LAUNCH(k_scatter_rows<uint16_t>, dim3(ss_div_up(n_src * chunks, 256)), dim3(256), 0, stream,
+                       (const uint16_t*)src, idx, (uint16_t*)dst, n_src, chunks);
+  }
+  SS_CHECK_LAUNCH();
+  return SS_OK;
+}
+
+// out[s][c] = reduce_{j in [ptr[s], ptr[s+1])} src[indices ? indices[j] : j][c]   (fp32 accumulate)
+template <typename T>
+__global__ void k_segment_reduce(const T* __restrict__ src, const int32_t* __restrict__ indices,
+                                 const int32_t* __restrict__ ptr, T* __restrict__ out, int64_t n_seg, int C, int mean) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_seg * C) return;
+  int64_t s = gid / C; int c = (int)(gid - s * C);
+  int b = ptr[s], e = ptr[s + 1];
+  float acc = 0.f;
+  for (int j = b; j < e; ++j) {
+    int64_t r = indices ? indices[j] : j;
+    acc += ElemIO<T>::load(src + r * C + c);
+  }
+  if (mean && e > b) acc /= (float)(e - b);
+  ElemIO<T>::store(out + gid, acc);
+}
+// dsrc[i][c] = dout[cluster[i]][c] * (mean ? 1/count : 1)
+template <typename T>
+__global__ void k_segment_bcast(const T* __restrict__ dout, const int32_t* __restrict__ cluster,
+                                const int32_t* __restrict__ ptr, T* __restrict__ dsrc, int64_t n, int C, int mean) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * C) return;
+  int64_t i = gid / C; int c = (int)(gid - i * C);
+  int s = cluster[i];
+  float v = ElemIO<T>::load(dout + (int64_t)s * C + c);
+  if (mean) v /= (float)(ptr[s + 1] - ptr[s]);
+  ElemIO<T>::store(dsrc + gid, v);
+}
+// dst[i][c] = a[i][c] + b[idx[i]][c]
+template <typename T>
+__global__ void k_gather_add(const T* __restrict__ a, const T* __restrict__ b, const int32_t* __restrict__ idx,
+                             T* __restrict__ dst, int64_t n, int C) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * C) return;
+  int64_t i = gid / C; int c = (int)(gid - i * C);
+  float v = ElemIO<T>::load(a + gid) + ElemIO<T>::load(b + (int64_t)idx[i] * C + c);
+  ElemIO<T>::store(dst + gid, v);
+}
+
+extern "C" int ss_segment_reduce(const void* src, const int32_t* indices, const int32_t* idx_ptr, void* out,
+                                 int64_t n_seg, int channels, int dtype, int mean, hipStream_t stream) {
+  if (n_seg < 0 || channels <= 0) return SS_ERR_ARG;
+  if (n_seg == 0) return SS_OK;
+  dim3 g(ss_div_up(n_seg * channels, 256)), b(256);
+  if (dtype == SS_F32)
+    SS_LAUNCH(k_segment_reduce<float>, g, b, 0, stream, (const float*)src, indices, idx_ptr, (float*)out, n_seg, channels, mean);
+  else if (dtype == SS_BF16)
+    SS_LAUNCH(k_segment_reduce<unsigned short>, g, b, 0, stream, (const unsigned short*)src, indices, idx_ptr, (unsigned short*)out, n_seg, channels, mean);
+  else return SS_ERR_ARG;
+  SS_CHECK_LAUNCH();
+  return SS_OK;
+}
+extern "C" int ss_segment_bcast(const void* dout, const int32_t* cluster, const int32_t* idx_ptr, void* dsrc, int64_t n,
+                                int channels, int dtype, int mean, hipStream_t stream) {
+  if (n < 0 || channels <= 0) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  dim3 g(ss_div_up(n * channels, 256)), b(256);
+  if (dtype == SS_F32)
+    SS_LAUNCH(k_segment_bcast<float>, g, b, 0, stream, (const float*)dout, cluster, idx_ptr, (float*)dsrc, n, channels, mean);
+  else if (dtype == SS_BF16)
+    SS_LAUNCH(k_segment_bcast<unsigned short>, g, b, 0, stream, (const unsigned short*)dout, cluster, idx_ptr, (unsigned short*)dsrc, n, channels, mean);
+  else return SS_ERR_ARG;
+  SS_CHECK_LAUNCH();
+  return SS_OK;
+}
+extern "C" int ss_gather_add_rows(const void* a, const void* b, const int32_t* idx, void* dst, int64_t n, int channels,
+                                  int dtype, hipStream_t stream) {
+  if (n < 0 || channels <= 0) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  dim3 g(ss_div_up(n * channels, 256)), bl(256);
+  if (dtype == SS_F32)
+    SS_LAUNCH(k_gather_add<float>, g, bl, 0, stream, (const float*)a, (const float*)b, idx, (float*)dst, n, channels);
+  else if (dtype == SS_BF16)
+    SS_LAUNCH(k_gather_add<unsigned short>, g, bl, 0, stream, (const unsigned short*)a, (const unsigned short*)b, idx, (unsigned short*)dst, n, channels);
+  else return SS_ERR_ARG;
+  SS_CHECK_LAUNCH();
+  return SS_OK;
+}

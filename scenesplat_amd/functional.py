@@ -1,0 +1,131 @@
+"""Differentiable ops of the PTv3 hot path: torch.autograd.Function shells around the HIP
+kernels (forward and backward are separate C-ABI entry points).
+
+  window_attention   <- flash_attn_varlen_qkvpacked_func + the [order]/[inverse] row gathers
+                        around it (ptv3:184-216), gather/scatter fused into the kernels
+  segment_mean       <- torch_scatter.segment_csr(proj(feat)[indices], idx_ptr, "mean") (ptv3:416-418)
+  unpool_add         <- parent.feat + point.feat[pooling_inverse]                      (ptv3:478)
+  subm_conv3d        <- spconv.SubMConv3d on a cached rulebook                         (ptv3:278-284,499-506)
+"""
+import torch
+
+from . import native as nv
+
+
+class _WindowAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, win, num_heads, scale, impl):
+        qkv = qkv.contiguous()
+        out, lse = nv.window_attn_fwd(qkv, win, num_heads, scale, impl)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.win, ctx.num_heads, ctx.scale, ctx.impl = win, num_heads, scale, impl
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        dqkv = nv.window_attn_bwd(qkv, out, dout.contiguous().to(qkv.dtype), lse, ctx.win, ctx.num_heads, ctx.scale, ctx.impl)
+        return dqkv, None, None, None, None
+
+
+def window_attention(qkv, win, num_heads, scale, impl=nv.ATTN_SIMT):
+    """qkv (n, 3C) in memory row order -> (n, C); windows/padding per `win` (plan.WindowIndex)."""
+    return _WindowAttention.apply(qkv, win, num_heads, scale, impl)
+
+
+class _SegmentMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, level):
+        src = src.contiguous()
+        ctx.level = level
+        return nv.segment_reduce(src, level.indices, level.idx_ptr, level.n, True)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lv = ctx.level
+        return nv.segment_bcast(dout.contiguous(), lv.cluster, lv.idx_ptr, True), None
+
+
+def segment_mean(src, level):
+    """Pool rows of the finer level into `level` (the coarser one): mean over each cluster."""
+    return _SegmentMean.apply(src, level)
+
+
+class _UnpoolAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, skip, up, level):
+        ctx.level = level
+        return nv.gather_add_rows(skip.contiguous(), up.contiguous(), level.cluster)
+
+    @staticmethod
+    def backward(ctx, g):
+        lv = ctx.level
+        g = g.contiguous()
+        return g, nv.segment_reduce(g, lv.indices, lv.idx_ptr, lv.n, False), None
+
+
+def unpool_add(skip, up, level):
+    """skip (n_fine, C) + up (n_coarse, C)[pooling_inverse]; `level` is the coarse level."""
+    return _UnpoolAdd.apply(skip, up, level)
+
+
+class _SubMConv3d(torch.autograd.Function):
+    """Per-tap gather (HIP) + dense GEMM accumulate (hipBLASLt through torch.addmm_).
+    Rulebook symmetry (nbr[i][t]=j <=> nbr[j][T-1-t]=i) turns dgrad into the same gather form;
+    it holds when voxels are unique per batch element.  With duplicate voxels (Mix3D batches)
+    dgrad falls back to an index_add scatter so the gradient stays exact."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias, nbr, has_dup, compute_dtype):
+        taps, n = nbr.shape
+        cout = weight.shape[0]
+        x = feat.to(compute_dtype).contiguous()
+        w = weight.reshape(cout, taps, -1).to(compute_dtype)
+        out = torch.zeros((n, cout), dtype=compute_dtype, device=feat.device) if bias is None else \
+            bias.to(compute_dtype).unsqueeze(0).repeat(n, 1)
+        buf = torch.empty_like(x)
+        for t in range(taps):
+            nv.gather_rows(x, nbr[t], out=buf)
+            out.addmm_(buf, w[:, t, :].t())
+        ctx.save_for_backward(x, weight, nbr)
+        ctx.has_bias, ctx.has_dup, ctx.compute_dtype, ctx.in_dtype = bias is not None, has_dup, compute_dtype, feat.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, nbr = ctx.saved_tensors
+        taps, n = nbr.shape
+        cout = weight.shape[0]
+        cd = ctx.compute_dtype
+        g = dout.to(cd).contiguous()
+        w = weight.reshape(cout, taps, -1).to(cd)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros_like(x)
+            if not ctx.has_dup:
+                buf = torch.empty_like(g)
+                for t in range(taps):
+                    nv.gather_rows(g, nbr[t], out=buf)
+                    dx.addmm_(buf, w[:, taps - 1 - t, :])
+            else:
+                for t in range(taps):
+                    rows = torch.nonzero(nbr[t] >= 0, as_tuple=True)[0]
+                    if rows.numel():
+                        dx.index_add_(0, nbr[t][rows].long(), g[rows] @ w[:, t, :])
+            dx = dx.to(ctx.in_dtype)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((taps, cout, x.shape[1]), dtype=cd, device=x.device)
+            buf = torch.empty_like(x)
+            gt = g.t()
+            for t in range(taps):
+                nv.gather_rows(x, nbr[t], out=buf)
+                torch.mm(gt, buf, out=dw[t])
+            dw = dw.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g.sum(0).to(weight.dtype)
+        return dx, dw, db, None, None, None
+
+
+def subm_conv3d(feat, weight, bias, nbr, has_dup=False, compute_dtype=torch.float32):
+    """weight (Cout, k, k, k, Cin) as in the reference checkpoints; nbr (k^3, n) tap-major."""
+    return _SubMConv3d.apply(feat, weight, bias, nbr, has_dup, compute_dtype)

@@ -1,0 +1,240 @@
+"""Tensor-level wrappers over the C-ABI (include/scenesplat_hip.h).
+
+PyTorch supplies device memory and the current HIP stream only; every call here lands in a
+hand-written HIP kernel.  Operands are validated on the host (device, dtype, contiguity,
+shape) before any launch; a CPU tensor is an error -- there is no fallback path."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+F32, BF16 = 0, 1
+ATTN_SIMT, ATTN_MFMA = 0, 1
+ORDER_IDS = {"z": 0, "z-trans": 1, "hilbert": 2, "hilbert-trans": 3}
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, dtype=None, name="tensor", shape=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: scenesplat_amd ops need a GPU tensor (no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise RuntimeError(f"unsupported feature dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def lib():
+    return _lib.load()
+
+
+# ---- serialization ------------------------------------------------------------------------
+def grid_coord_max(gc32):
+    _req(gc32, torch.int32, "grid_coord")
+    out = torch.empty(1, dtype=torch.int32, device=gc32.device)
+    check(lib().ss_grid_coord_max(_p(gc32), gc32.shape[0], _p(out), _stream()), "ss_grid_coord_max")
+    return out
+
+
+def offsets_to_batch(offsets32, n):
+    _req(offsets32, torch.int32, "offsets")
+    batch = torch.empty(n, dtype=torch.int32, device=offsets32.device)
+    check(lib().ss_offsets_to_batch(_p(offsets32), offsets32.numel(), n, _p(batch), _stream()), "ss_offsets_to_batch")
+    return batch
+
+
+def serialize_encode(gc32, batch32, depth, order_names):
+    n = gc32.shape[0]
+    _req(gc32, torch.int32, "grid_coord", (n, 3))
+    if batch32 is not None:
+        _req(batch32, torch.int32, "batch", (n,))
+    k = len(order_names)
+    ids = (ctypes.c_int * k)(*[ORDER_IDS[o] for o in order_names])
+    codes = torch.empty((k, n), dtype=torch.int64, device=gc32.device)
+    check(lib().ss_serialize_encode(_p(gc32), _p(batch32), n, int(depth), ids, k, _p(codes), _stream()),
+          "ss_serialize_encode")
+    return codes
+
+
+def argsort_i64(keys, key_bits, want_inverse=True, want_sorted=True):
+    """keys (K, n) int64 >= 0 -> order (K,n) int32 [, inverse (K,n) int32, sorted keys (K,n) int64]; stable."""
+    _req(keys, torch.int64, "keys")
+    K, n = keys.shape
+    dev = keys.device
+    order = torch.empty((K, n), dtype=torch.int32, device=dev)
+    inverse = torch.empty((K, n), dtype=torch.int32, device=dev) if want_inverse else None
+    skeys = torch.empty((K, n), dtype=torch.int64, device=dev) if want_sorted else None
+    nb = lib().ss_argsort_workspace_bytes(n, K)
+    ws = _ws(nb, dev)
+    check(lib().ss_argsort_i64(_p(keys), K, n, int(max(1, min(64, key_bits))), _p(order), _p(inverse), _p(skeys),
+                               _p(ws), ws.numel(), _stream()), "ss_argsort_i64")
+    return order, inverse, skeys
+
+
+def count_duplicates(sorted_keys_row):
+    _req(sorted_keys_row, torch.int64, "sorted_keys")
+    cnt = torch.empty(1, dtype=torch.int32, device=sorted_keys_row.device)
+    check(lib().ss_count_duplicates(_p(sorted_keys_row), sorted_keys_row.numel(), _p(cnt), _stream()),
+          "ss_count_duplicates")
+    return cnt
+
+
+def pool_partition(code0, order0, shift_bits):
+    n = code0.numel()
+    _req(code0, torch.int64, "code0", (n,)); _req(order0, torch.int32, "order0", (n,))
+    dev = code0.device
+    cluster = torch.empty(n, dtype=torch.int32, device=dev)
+    idx_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    head = torch.empty(n, dtype=torch.int32, device=dev)
+    n_out = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = _ws(lib().ss_pool_partition_workspace_bytes(n), dev)
+    check(lib().ss_pool_partition(_p(code0), _p(order0), n, int(shift_bits), _p(cluster), _p(idx_ptr), _p(head),
+                                  _p(n_out), _p(ws), ws.numel(), _stream()), "ss_pool_partition")
+    return cluster, idx_ptr, head, n_out
+
+
+def pool_level_attrs(head, n_out, gc32, batch32, codes, pool_depth):
+    K, n_in = codes.shape
+    _req(codes, torch.int64, "codes"); _req(gc32, torch.int32, "grid_coord", (n_in, 3)); _req(batch32, torch.int32, "batch", (n_in,))
+    _req(head, torch.int32, "head")
+    if head.numel() < n_out:
+        raise RuntimeError("head shorter than n_out")
+    dev = codes.device
+    gco = torch.empty((n_out, 3), dtype=torch.int32, device=dev)
+    bo = torch.empty(n_out, dtype=torch.int32, device=dev)
+    co = torch.empty((K, n_out), dtype=torch.int64, device=dev)
+    check(lib().ss_pool_level_attrs(_p(head), n_out, n_in, _p(gc32), _p(batch32), _p(codes), K, int(pool_depth),
+                                    _p(gco), _p(bo), _p(co), _stream()), "ss_pool_level_attrs")
+    return gco, bo, co
+
+
+def window_index(order_row, offsets, offsets_pad, patch, n_pad):
+    _req(order_row, torch.int32, "order"); _req(offsets, torch.int32, "offsets"); _req(offsets_pad, torch.int32, "offsets_pad")
+    B = offsets.numel() - 1
+    dev = order_row.device
+    gidx = torch.empty(n_pad, dtype=torch.int32, device=dev)
+    sidx = torch.empty(n_pad, dtype=torch.int32, device=dev)
+    check(lib().ss_window_index(_p(order_row), _p(offsets), _p(offsets_pad), B, int(patch), n_pad, _p(gidx), _p(sidx),
+                                _stream()), "ss_window_index")
+    return gidx, sidx
+
+
+def subm_rulebook(gc32, batch32, depth, zkeys_sorted, zorder, swap_xy, ksize):
+    n = gc32.shape[0]
+    _req(gc32, torch.int32, "grid_coord", (n, 3)); _req(batch32, torch.int32, "batch", (n,))
+    _req(zkeys_sorted, torch.int64, "zkeys_sorted", (n,)); _req(zorder, torch.int32, "zorder", (n,))
+    nbr = torch.empty((ksize ** 3, n), dtype=torch.int32, device=gc32.device)
+    check(lib().ss_subm_rulebook(_p(gc32), _p(batch32), n, int(depth), _p(zkeys_sorted), _p(zorder), int(swap_xy),
+                                 int(ksize), _p(nbr), _stream()), "ss_subm_rulebook")
+    return nbr
+
+
+# ---- rows ------------------------------------------------------------------------------------
+def gather_rows(src, idx, out=None):
+    """out[i] = src[idx[i]] (zero row where idx < 0).  src (m, C)."""
+    _req(src, None, "src"); _req(idx, torch.int32, "idx")
+    n = idx.numel()
+    if src.dim() != 2:
+        raise RuntimeError("src must be (rows, C)")
+    rb = src.shape[1] * src.element_size()
+    if out is None:
+        out = torch.empty((n, src.shape[1]), dtype=src.dtype, device=src.device)
+    else:
+        _req(out, src.dtype, "out", (n, src.shape[1]))
+    check(lib().ss_gather_rows(_p(src), _p(idx), _p(out), n, rb, _stream()), "ss_gather_rows")
+    return out
+
+
+def scatter_rows(src, idx, dst):
+    """dst[idx[i]] = src[i] for idx[i] >= 0 (idx unique)."""
+    _req(src, None, "src"); _req(idx, torch.int32, "idx", (src.shape[0],)); _req(dst, src.dtype, "dst")
+    if dst.shape[1] != src.shape[1]:
+        raise RuntimeError("row width mismatch")
+    rb = src.shape[1] * src.element_size()
+    check(lib().ss_scatter_rows(_p(src), _p(idx), _p(dst), src.shape[0], rb, _stream()), "ss_scatter_rows")
+    return dst
+
+
+def gather_add_rows(a, b, idx):
+    n, C = a.shape
+    _req(a, None, "a"); _req(b, a.dtype, "b"); _req(idx, torch.int32, "idx", (n,))
+    if b.shape[1] != C:
+        raise RuntimeError("channel mismatch")
+    out = torch.empty_like(a)
+    check(lib().ss_gather_add_rows(_p(a), _p(b), _p(idx), _p(out), n, C, dtype_code(a), _stream()), "ss_gather_add_rows")
+    return out
+
+
+def segment_reduce(src, indices, idx_ptr, n_seg, mean):
+    _req(src, None, "src"); _req(idx_ptr, torch.int32, "idx_ptr")
+    if indices is not None:
+        _req(indices, torch.int32, "indices")
+    if idx_ptr.numel() < n_seg + 1:
+        raise RuntimeError("idx_ptr shorter than n_seg+1")
+    C = src.shape[1]
+    out = torch.empty((n_seg, C), dtype=src.dtype, device=src.device)
+    check(lib().ss_segment_reduce(_p(src), _p(indices), _p(idx_ptr), _p(out), n_seg, C, dtype_code(src), int(mean),
+                                  _stream()), "ss_segment_reduce")
+    return out
+
+
+def segment_bcast(dout, cluster, idx_ptr, mean):
+    _req(dout, None, "dout"); _req(cluster, torch.int32, "cluster"); _req(idx_ptr, torch.int32, "idx_ptr")
+    n, C = cluster.numel(), dout.shape[1]
+    dsrc = torch.empty((n, C), dtype=dout.dtype, device=dout.device)
+    check(lib().ss_segment_bcast(_p(dout), _p(cluster), _p(idx_ptr), _p(dsrc), n, C, dtype_code(dout), int(mean),
+                                 _stream()), "ss_segment_bcast")
+    return dsrc
+
+
+# ---- attention -------------------------------------------------------------------------------
+def window_attn_fwd(qkv, win, num_heads, scale, impl):
+    n, C3 = qkv.shape
+    C = C3 // 3
+    _req(qkv, None, "qkv")
+    if n != win.n:
+        raise RuntimeError(f"qkv rows {n} != window index rows {win.n}")
+    out = torch.empty((n, C), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((win.n_pad, num_heads), dtype=torch.float32, device=qkv.device)
+    check(lib().ss_window_attn_fwd(_p(qkv), _p(win.gidx), _p(win.sidx), _p(win.win_start), win.num_windows,
+                                   win.max_window, n, win.n_pad, C, num_heads, float(scale), dtype_code(qkv), int(impl),
+                                   _p(out), _p(lse), _stream()), "ss_window_attn_fwd")
+    return out, lse
+
+
+def window_attn_bwd(qkv, out, dout, lse, win, num_heads, scale, impl):
+    n, C3 = qkv.shape
+    C = C3 // 3
+    _req(qkv, None, "qkv"); _req(out, qkv.dtype, "out", (n, C)); _req(dout, qkv.dtype, "dout", (n, C))
+    _req(lse, torch.float32, "lse", (win.n_pad, num_heads))
+    dqkv = torch.empty_like(qkv)
+    nb = lib().ss_window_attn_bwd_workspace_bytes(n, win.n_pad, C, num_heads, dtype_code(qkv))
+    ws = _ws(nb, qkv.device)
+    check(lib().ss_window_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(win.gidx), _p(win.sidx), _p(win.win_start),
+                                   win.num_windows, win.max_window, n, win.n_pad, C, num_heads, float(scale),
+                                   dtype_code(qkv), int(impl), _p(dqkv), _p(ws), ws.numel(), _stream()),
+          "ss_window_attn_bwd")
+    return dqkv

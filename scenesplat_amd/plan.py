@@ -1,0 +1,183 @@
+"""ScenePlan: the integer structure of one forward pass, built once on the GPU.
+
+Everything PTv3 derives from grid coordinates alone -- 4-curve codes/orders per resolution
+level, the grid-pool partitions, attention window indices with duplicate padding, submanifold
+rulebooks -- is computed here by the HIP kernels of csrc/serialize.hip before any float work
+starts, so the float pipeline runs without host round trips.  Host syncs: one for
+(serialization depth, batch offsets) and one per pooling level (pooled size + offsets).
+
+Mirrors, for the structure it produces (reference file:line):
+  Point.serialization            pointcept/models/utils/structure.py:47-102
+  SerializedPooling (int part)   point_transformer_v3m1_base.py:372-428
+  get_padding_and_inverse        point_transformer_v3m1_base.py:114-170
+  Point.sparsify / spconv pairs  structure.py:104-140
+"""
+import torch
+
+from . import native as nv
+
+
+class WindowIndex:
+    """Padded-slot -> row maps of one (level, curve, patch size): gidx/sidx (n_pad) and
+    win_start == cu_seqlens (ptv3:165-169)."""
+
+    __slots__ = ("gidx", "sidx", "win_start", "num_windows", "max_window", "n", "n_pad", "offsets_pad")
+
+    def __init__(self, gidx, sidx, win_start, num_windows, max_window, n, n_pad, offsets_pad):
+        self.gidx, self.sidx, self.win_start = gidx, sidx, win_start
+        self.num_windows, self.max_window, self.n, self.n_pad = num_windows, max_window, n, n_pad
+        self.offsets_pad = offsets_pad
+
+
+def window_layout(counts, patch):
+    """Host-side closed form of the reference padding rule: returns (offsets_pad, win_start).
+    An element with more than `patch` points is padded to a multiple of `patch`; smaller
+    elements form one short window (ptv3:126-136, 156-164)."""
+    off_pad, win = [0], []
+    for c in counts:
+        cp = (c + patch - 1) // patch * patch if c > patch else c
+        win.extend(range(off_pad[-1], off_pad[-1] + cp, patch) if cp > 0 else [])
+        off_pad.append(off_pad[-1] + cp)
+    win.append(off_pad[-1])
+    return off_pad, win
+
+
+class Level:
+    def __init__(self, gc32, batch32, offsets, depth, codes, order, inverse, codes_sorted, curves):
+        self.grid_coord, self.batch = gc32, batch32
+        self.offsets = list(offsets)  # host, leading 0, len B+1
+        self.depth = depth
+        self.n = gc32.shape[0]
+        self.device = gc32.device
+        # rows of these (K, n) buffers are in the config's curve order; `curves[j]` = row used at index j
+        self.codes, self.order, self.inverse, self.codes_sorted = codes, order, inverse, codes_sorted
+        self.curves = list(curves)
+        self.curve_names = None
+        # link to the finer level (set on pooled levels): segment_csr operands
+        self.cluster = self.idx_ptr = self.indices = None
+        self.has_duplicates = False
+        self._windows, self._nbr = {}, {}
+
+    # -- accessors in *current* (possibly shuffled) curve order --------------------------------
+    def order_row(self, j):
+        return self.order[self.curves[j]]
+
+    def inverse_row(self, j):
+        return self.inverse[self.curves[j]]
+
+    def code_row(self, j):
+        return self.codes[self.curves[j]]
+
+    @property
+    def counts(self):
+        return [self.offsets[i + 1] - self.offsets[i] for i in range(len(self.offsets) - 1)]
+
+    def window(self, j, patch):
+        key = (self.curves[j], int(patch))
+        w = self._windows.get(key)
+        if w is None:
+            off_pad, win = window_layout(self.counts, int(patch))
+            dev = self.device
+            t_off = torch.tensor(self.offsets, dtype=torch.int32, device=dev)
+            t_offp = torch.tensor(off_pad, dtype=torch.int32, device=dev)
+            t_win = torch.tensor(win, dtype=torch.int32, device=dev)
+            gidx, sidx = nv.window_index(self.order_row(j), t_off, t_offp, patch, off_pad[-1])
+            maxw = max([win[i + 1] - win[i] for i in range(len(win) - 1)] or [0])
+            w = WindowIndex(gidx, sidx, t_win, len(win) - 1, maxw, self.n, off_pad[-1], off_pad)
+            self._windows[key] = w
+        return w
+
+    def neighbors(self, ksize):
+        """(k^3, n) int32 tap-major rulebook, shared by every conv of this level (indice_key)."""
+        nb = self._nbr.get(ksize)
+        if nb is None:
+            zrow, swap = None, 0
+            for r, name in enumerate(self.curve_names):
+                if name == "z":
+                    zrow, swap = r, 0
+                    break
+                if name == "z-trans" and zrow is None:
+                    zrow, swap = r, 1
+            if zrow is None:
+                codes = nv.serialize_encode(self.grid_coord, self.batch, self.depth, ["z"])
+                bits = _key_bits(self.depth, len(self.offsets) - 1)
+                zo, _, zs = nv.argsort_i64(codes, bits, want_inverse=False)
+                zkeys, zorder, swap = zs[0], zo[0], 0
+            else:
+                zkeys, zorder = self.codes_sorted[zrow], self.order[zrow]
+            nb = nv.subm_rulebook(self.grid_coord, self.batch, self.depth, zkeys, zorder, swap, ksize)
+            self._nbr[ksize] = nb
+        return nb
+
+
+class ScenePlan:
+    def __init__(self, levels, order_names):
+        self.levels, self.order_names = levels, order_names
+
+
+def _key_bits(depth, num_batches):
+    return max(1, 3 * depth + max(0, (int(num_batches) - 1).bit_length()))
+
+
+@torch.no_grad()
+def build_plan(grid_coord, offset, order_names, strides, perms=None, depth=None):
+    """grid_coord (N,3) integer GPU tensor; offset (B,) cumulative counts (GPU or CPU).
+    perms: list (1 + len(strides)) of curve permutations (level 0 first) or None for identity
+    at level 0 and identity at pooled levels.  The caller draws them (torch.randperm on the
+    CPU RNG, as the reference does: structure.py:94-98, ptv3:408-412)."""
+    if not grid_coord.is_cuda:
+        raise RuntimeError("build_plan: grid_coord must live on the GPU (no CPU fallback)")
+    dev = grid_coord.device
+    K = len(order_names)
+    gc32 = grid_coord.to(torch.int32).contiguous()
+    n = gc32.shape[0]
+    off_dev = offset.to(device=dev, dtype=torch.int32).contiguous()
+    B = off_dev.numel()
+    gmax = nv.grid_coord_max(gc32)
+    host = torch.cat([gmax, off_dev]).cpu().tolist()            # sync 1: depth + offsets
+    if depth is None:
+        depth = int(host[0]).bit_length()
+    if depth > 16 or 3 * depth + int(B).bit_length() > 63:
+        raise ValueError("serialization depth out of range (structure.py:69,74)")
+    offsets = [0] + [int(v) for v in host[1:]]
+    if offsets[-1] != n:
+        raise ValueError(f"offset[-1]={offsets[-1]} != number of points {n}")
+    batch32 = nv.offsets_to_batch(off_dev, n)
+    codes = nv.serialize_encode(gc32, batch32, depth, order_names)
+    order, inverse, csorted = nv.argsort_i64(codes, _key_bits(depth, B))
+    curves = list(range(K)) if perms is None else [int(v) for v in perms[0]]
+    lv = Level(gc32, batch32, offsets, depth, codes, order, inverse, csorted, curves)
+    lv.curve_names = list(order_names)
+    dup = nv.count_duplicates(csorted[0])
+    levels = [lv]
+    for s, stride in enumerate(strides):
+        prev = levels[-1]
+        pd = (int(stride) - 1).bit_length()
+        if pd > prev.depth:
+            pd = 0
+        cluster, idx_ptr, head, _ = nv.pool_partition(prev.code_row(0), prev.order_row(0), 3 * pd)
+        ends = torch.tensor([max(e - 1, 0) for e in prev.offsets[1:]], dtype=torch.int64, device=dev)
+        o0 = prev.order_row(0)
+        new_off = (cluster[o0[ends].long()] + 1)
+        if s == 0:
+            new_off = torch.cat([new_off, dup])
+        new_off = new_off.cpu().tolist()                              # sync per level: pooled offsets
+        if s == 0:
+            levels[0].has_duplicates = new_off.pop() > 0
+        for b in range(B):  # empty batch elements own no cluster
+            if prev.offsets[b + 1] == prev.offsets[b]:
+                new_off[b] = new_off[b - 1] if b > 0 else 0
+        n_out = int(new_off[-1])
+        gco, bo, co = nv.pool_level_attrs(head, n_out, prev.grid_coord, prev.batch, prev.codes, pd)
+        ndepth = prev.depth - pd
+        o, inv, cs = nv.argsort_i64(co, _key_bits(ndepth, B))
+        base = prev.curves
+        curves = list(base) if perms is None else [base[int(v)] for v in perms[s + 1]]
+        nl = Level(gco, bo, [0] + [int(v) for v in new_off], ndepth, co, o, inv, cs, curves)
+        nl.curve_names = list(order_names)
+        nl.cluster, nl.idx_ptr, nl.indices = cluster, idx_ptr, o0
+        nl.has_duplicates = False  # pooled levels have unique voxels by construction
+        levels.append(nl)
+    if len(strides) == 0:
+        levels[0].has_duplicates = int(dup.item()) > 0
+    return ScenePlan(levels, list(order_names))

@@ -1,0 +1,183 @@
+"""Vision-language distillation head: ``LangPretrainer`` and its three criteria.
+
+Registry names, constructor kwargs and forward contracts follow the reference
+(pointcept/models/default.py:77-176; pointcept/models/losses/misc.py:247-421;
+pointcept/models/losses/builder.py:13-31).  The math is restated sync-free for the GPU:
+boolean-mask gathers (``pred[valid]``, a device->host sync each) become masked reductions, and
+AggregatedContrastiveLoss's per-class Python loop (nonzero / randperm / sum per class,
+misc.py:364-388) becomes one keyed radix sort + one CSR segment-sum over (class, half) groups
+with fixed-shape masked cross-entropy, keeping the reference's semantics exactly: rows with
+mask & segment != -1, classes with >= 100 rows, a uniformly random permutation of each class
+split at n//2, group *sums*, L2-normalise, symmetric CE at temperature tau.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import native as nv
+from .registry import LOSSES, MODELS, build_model
+from .structure import Point
+
+
+@LOSSES.register_module()
+class CosineSimilarity(nn.Module):
+    def __init__(self, reduction="mean", loss_weight=1.0):
+        super().__init__()
+        self.reduction, self.loss_weight = reduction, loss_weight
+
+    def forward(self, pred, target, valid_feat_mask, **kwargs):
+        m = valid_feat_mask.to(pred.dtype)
+        loss = ((1 - F.cosine_similarity(pred, target.to(pred.dtype), dim=1)) * m).sum()
+        if self.reduction == "mean":
+            loss = loss / m.sum().clamp(min=1.0)
+        return self.loss_weight * loss
+
+
+@LOSSES.register_module()
+class L2Loss(nn.Module):
+    def __init__(self, reduction="mean", loss_weight=1.0):
+        super().__init__()
+        self.reduction, self.loss_weight = reduction, loss_weight
+
+    def forward(self, pred, target, valid_feat_mask, **kwargs):
+        m = valid_feat_mask.to(pred.dtype)
+        loss = (((pred - target.to(pred.dtype)) ** 2).sum(dim=1) * m).sum()
+        if self.reduction == "mean":
+            loss = loss / m.sum().clamp(min=1.0)
+        return self.loss_weight * loss
+
+
+class _GroupSum(torch.autograd.Function):
+    """G[g] = sum of rows listed in CSR (indices, ptr); backward broadcasts dG[group(row)]."""
+
+    @staticmethod
+    def forward(ctx, feat, indices, ptr, n_groups, row_group):
+        ctx.save_for_backward(row_group)
+        ctx.n = feat.shape[0]
+        return nv.segment_reduce(feat.contiguous(), indices, ptr, n_groups, False)
+
+    @staticmethod
+    def backward(ctx, dG):
+        (row_group,) = ctx.saved_tensors
+        # rows outside every group index the extra all-zero row
+        dGz = torch.cat([dG, dG.new_zeros(1, dG.shape[1])], 0).contiguous()
+        return nv.gather_rows(dGz, row_group), None, None, None, None
+
+
+@LOSSES.register_module()
+class AggregatedContrastiveLoss(nn.Module):
+    def __init__(self, temperature=0.2, reduction="mean", loss_weight=1.0, schedule="all", max_classes=256,
+                 min_count=100):
+        super().__init__()
+        self.temperature, self.reduction, self.loss_weight, self.schedule = temperature, reduction, loss_weight, schedule
+        self.max_classes, self.min_count = max_classes, min_count
+        if "last_" in schedule:
+            self.last_percent = float(schedule.split("_")[-1]) / 100
+
+    def forward(self, pred, target, valid_feat_mask, segment, epoch_progress=None, rand_keys=None, **kwargs):
+        dev = pred.device
+        if "last_" in self.schedule and epoch_progress is not None:
+            if epoch_progress <= (1 - self.last_percent):
+                return torch.tensor(0.0, device=dev)
+        elif self.schedule == "skip":
+            return torch.tensor(0.0, device=dev)
+        if segment is None:
+            return torch.tensor(0.0, device=dev)
+        N, Cc = pred.shape[0], self.max_classes
+        valid = (valid_feat_mask > 0) & (segment != -1)
+        if rand_keys is None:
+            rand_keys = torch.rand(N, device=dev)
+        # sort rows by (class, random key); invalid rows go to a sentinel class at the end
+        cls = torch.where(valid, segment.long().clamp(0, Cc - 1), torch.full_like(segment.long(), Cc))
+        keyi = (rand_keys.double() * (1 << 31)).long().clamp(0, (1 << 31) - 1)
+        comp = ((cls << 31) | keyi).unsqueeze(0).contiguous()
+        order, _, _ = nv.argsort_i64(comp, 31 + (Cc).bit_length(), want_inverse=False, want_sorted=False)
+        order = order[0]
+        counts = torch.zeros(Cc + 1, dtype=torch.int64, device=dev).scatter_add_(0, cls, torch.ones_like(cls))
+        starts = torch.cumsum(counts, 0) - counts                      # class start in sorted order
+        half = counts // 2
+        # CSR over 2*Cc groups: [a_0, b_0, a_1, b_1, ...]
+        ptr = torch.stack([starts[:Cc], starts[:Cc] + half[:Cc]], 1).reshape(-1)
+        ptr = torch.cat([ptr, starts[Cc:Cc + 1]]).to(torch.int32).contiguous()
+        # group of every row (for the backward broadcast); rows of the sentinel class -> 2*Cc (zero row)
+        rank = torch.empty(N, dtype=torch.int64, device=dev)
+        rank[order.long()] = torch.arange(N, device=dev)
+        in_b = (rank - starts[cls]) >= half[cls]
+        row_group = torch.where(cls < Cc, 2 * cls + in_b.long(), torch.full_like(cls, 2 * Cc)).to(torch.int32)
+        G = _GroupSum.apply(pred.float(), order.contiguous(), ptr, 2 * Cc, row_group.contiguous())
+        A, B = F.normalize(G[0::2], p=2, dim=1), F.normalize(G[1::2], p=2, dim=1)
+        used = (counts[:Cc] >= self.min_count) & (half[:Cc] > 0)
+        nused = used.sum()
+        neg = torch.finfo(torch.float32).min
+        logits = (A @ B.t()) / self.temperature
+        colmask = used.unsqueeze(0)
+
+        def ce(lg):
+            lg = torch.where(colmask, lg, torch.full_like(lg, neg))
+            per = torch.logsumexp(lg, dim=1) - lg.diagonal()
+            return (per * used).sum() / nused.clamp(min=1)
+
+        loss = (ce(logits) + ce(logits.t())) / 2.0
+        if self.reduction == "sum":
+            loss = loss * nused
+        return self.loss_weight * loss * (nused > 0)
+
+
+class Criteria(object):
+    """pointcept/models/losses/builder.py:13-27"""
+
+    def __init__(self, cfg=None):
+        self.cfg = cfg if cfg is not None else []
+        self.criteria = [LOSSES.build(cfg=c) for c in self.cfg]
+
+    def __call__(self, pred, target, **kwargs):
+        if len(self.criteria) == 0:
+            return pred
+        loss = 0
+        for c in self.criteria:
+            loss += c(pred, target, **kwargs)
+        return loss
+
+
+def build_criteria(cfg):
+    return Criteria(cfg)
+
+
+@MODELS.register_module()
+class LangPretrainer(nn.Module):
+    def __init__(self, backbone=None, criteria=None):
+        super().__init__()
+        self.backbone = build_model(backbone)
+        self.criteria = build_criteria(criteria)
+
+    def forward(self, input_dict, chunk_size=None):
+        if chunk_size is not None and chunk_size > 0 and input_dict["coord"].shape[0] > chunk_size:
+            return self._chunked_forward(input_dict, chunk_size)
+        point_feat = self.backbone(Point(input_dict))
+        point_feat["feat"] = F.normalize(point_feat["feat"].float(), p=2, dim=1)
+        if self.training:
+            loss = self.criteria(point_feat["feat"], input_dict["lang_feat"],
+                                 valid_feat_mask=input_dict["valid_feat_mask"],
+                                 segment=input_dict["segment"] if "segment" in input_dict.keys() else None,
+                                 epoch_progress=input_dict["epoch_progress"])
+            return dict(loss=loss)
+        return dict(point_feat=point_feat)
+
+    def _chunked_forward(self, input_dict, chunk_size):
+        """Contiguous index-range chunks processed independently (default.py:115-176)."""
+        N = input_dict["coord"].shape[0]
+        outs = []
+        for s in range(0, N, chunk_size):
+            e = min(s + chunk_size, N)
+            chunk = {k: v[s:e] for k, v in input_dict.items() if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == N}
+            chunk["offset"] = torch.tensor([e - s], device=input_dict["coord"].device)
+            feat = F.normalize(self.backbone(Point(chunk))["feat"].float(), p=2, dim=1)
+            if self.training:
+                outs.append(self.criteria(feat, chunk["lang_feat"], valid_feat_mask=chunk["valid_feat_mask"],
+                                          segment=chunk.get("segment", None),
+                                          epoch_progress=input_dict.get("epoch_progress", None)))
+            else:
+                outs.append(feat)
+        if self.training:
+            return dict(loss=torch.stack(outs).mean())
+        return dict(point_feat={"feat": torch.cat(outs, dim=0)})

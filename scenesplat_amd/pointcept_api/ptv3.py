@@ -1,0 +1,312 @@
+"""PT-v3m1 on the HIP hot path.
+
+Same registry name, constructor kwargs, ``forward(data_dict) -> Point`` contract and
+state-dict keys/shapes as the reference model
+(pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py:518-714; keys: SURVEY
+Appendix D), so released checkpoints load unchanged.  The execution model is different: the
+integer structure of the whole forward is planned once on the GPU (scenesplat_amd.plan) and
+each Block runs fused HIP ops -- rulebook conv, serialized-window attention with the
+[order]/[inverse] gathers folded into the kernel, CSR pooling -- around hipBLASLt GEMMs.
+
+Replicated reference behaviours that look like accidents but are what the released weights
+were trained with:
+  * the first Block after every unpooling convolves the *stale* sparse features
+    (proj_skip(skip) only): modules.py:64-75 + ptv3:476-478;
+  * SerializedPooling shuffles the curve order with torch.randperm even when the model's
+    shuffle_orders=False (ptv3:350,408-412,614-620);
+  * tail windows are topped up with points borrowed from the previous window (ptv3:145-154).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as SF
+from .. import native as nv
+from ..plan import build_plan
+from .registry import MODELS
+from .structure import Point
+
+# knobs of the execution (not of the model): attention kernel family and conv compute dtype
+RUNTIME = dict(attn_impl=nv.ATTN_SIMT, conv_dtype=None)  # conv_dtype None: follow the reference (fp32)
+
+
+class PointModule(nn.Module):
+    """Marker base class, as pointcept/models/modules.py:8-14."""
+
+
+class DropPath(nn.Module):
+    """Per-row stochastic depth == timm.layers.DropPath on (N, C) features (ptv3:314-316)."""
+
+    def __init__(self, p=0.0):
+        super().__init__()
+        self.p = float(p)
+
+    def forward(self, x):
+        if self.p == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.p
+        mask = x.new_empty((x.shape[0], 1)).bernoulli_(keep)
+        if keep > 0.0:
+            mask.div_(keep)
+        return x * mask
+
+
+class SubMConv3d(nn.Module):
+    """Parameter holder with spconv's layout: weight (Cout, k, k, k, Cin), optional bias."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True, indice_key=None):
+        super().__init__()
+        k = kernel_size
+        self.kernel_size, self.indice_key = k, indice_key
+        self.weight = nn.Parameter(torch.empty(out_channels, k, k, k, in_channels))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        nn.init.kaiming_uniform_(self.weight.view(out_channels, -1), a=5 ** 0.5)
+
+    def forward(self, feat, level):
+        cd = RUNTIME["conv_dtype"] or torch.float32
+        return SF.subm_conv3d(feat, self.weight, self.bias, level.neighbors(self.kernel_size),
+                              level.has_duplicates, cd)
+
+
+class SerializedAttention(PointModule):
+    def __init__(self, channels, num_heads, patch_size, qkv_bias=True, qk_scale=None, attn_drop=0.0,
+                 proj_drop=0.0, order_index=0, enable_rpe=False, enable_flash=True, upcast_attention=True,
+                 upcast_softmax=True):
+        super().__init__()
+        assert channels % num_heads == 0
+        if enable_rpe:
+            raise NotImplementedError("enable_rpe is off in every SceneSplat language config; not on the HIP path")
+        if attn_drop != 0.0 or proj_drop != 0.0:
+            raise NotImplementedError("attention / projection dropout are 0 in the reference configs")
+        self.channels, self.num_heads, self.patch_size = channels, num_heads, patch_size
+        self.scale = qk_scale or (channels // num_heads) ** -0.5
+        self.order_index = order_index
+        self.qkv = nn.Linear(channels, channels * 3, bias=qkv_bias)
+        self.proj = nn.Linear(channels, channels)
+
+    def forward(self, x, level):
+        win = level.window(self.order_index, self.patch_size)
+        qkv = self.qkv(x)
+        impl = RUNTIME["attn_impl"]
+        if impl == nv.ATTN_MFMA and qkv.dtype != torch.bfloat16:
+            feat = SF.window_attention(qkv.to(torch.bfloat16), win, self.num_heads, self.scale, impl).to(qkv.dtype)
+        else:
+            feat = SF.window_attention(qkv, win, self.num_heads, self.scale, impl)
+        return self.proj(feat)
+
+
+class MLP(nn.Module):
+    def __init__(self, in_channels, hidden_channels=None, out_channels=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        out_channels = out_channels or in_channels
+        hidden_channels = hidden_channels or in_channels
+        self.fc1 = nn.Linear(in_channels, hidden_channels)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_channels, out_channels)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class Block(PointModule):
+    def __init__(self, channels, num_heads, patch_size=48, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
+                 attn_drop=0.0, proj_drop=0.0, drop_path=0.0, norm_layer=nn.LayerNorm, act_layer=nn.GELU,
+                 pre_norm=True, order_index=0, cpe_indice_key=None, enable_rpe=False, enable_flash=True,
+                 upcast_attention=True, upcast_softmax=True):
+        super().__init__()
+        self.channels, self.pre_norm = channels, pre_norm
+        self.cpe = nn.Sequential(SubMConv3d(channels, channels, 3, bias=True, indice_key=cpe_indice_key),
+                                 nn.Linear(channels, channels), norm_layer(channels))
+        self.norm1 = nn.Sequential(norm_layer(channels))
+        self.attn = SerializedAttention(channels, num_heads, patch_size, qkv_bias, qk_scale, attn_drop, proj_drop,
+                                        order_index, enable_rpe, enable_flash, upcast_attention, upcast_softmax)
+        self.norm2 = nn.Sequential(norm_layer(channels))
+        self.mlp = nn.Sequential(MLP(channels, int(channels * mlp_ratio), channels, act_layer, proj_drop))
+        self.drop_path = nn.Sequential(DropPath(drop_path) if drop_path > 0.0 else nn.Identity())
+
+    def forward(self, x, conv_in, level):
+        """x: Point.feat; conv_in: sparse_conv_feat.features (differs from x only in the first
+        decoder block of a stage)."""
+        c = self.cpe[0](conv_in, level)
+        x = x + self.cpe[2](self.cpe[1](c))
+        h = self.norm1(x) if self.pre_norm else x
+        x = x + self.drop_path(self.attn(h, level))
+        if not self.pre_norm:
+            x = self.norm1(x)
+        h = self.norm2(x) if self.pre_norm else x
+        x = x + self.drop_path(self.mlp(h))
+        if not self.pre_norm:
+            x = self.norm2(x)
+        return x
+
+
+class SerializedPooling(PointModule):
+    def __init__(self, in_channels, out_channels, stride=2, norm_layer=None, act_layer=None, reduce="mean",
+                 shuffle_orders=True, traceable=True):
+        super().__init__()
+        if reduce != "mean":
+            raise NotImplementedError("only the 'mean' grid pool is on the HIP path (the reference default)")
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+        self.shuffle_orders = shuffle_orders
+        self.proj = nn.Linear(in_channels, out_channels)
+        self.norm = nn.Sequential(norm_layer(out_channels)) if norm_layer is not None else None
+        self.act = act_layer() if act_layer is not None else None
+
+    def forward(self, x, coarse_level):
+        x = SF.segment_mean(self.proj(x), coarse_level)
+        if self.norm is not None:
+            x = self.norm(x)
+        if self.act is not None:
+            x = self.act(x)
+        return x
+
+
+class SerializedUnpooling(PointModule):
+    def __init__(self, in_channels, skip_channels, out_channels, norm_layer=None, act_layer=None, traceable=False):
+        super().__init__()
+        self.proj = nn.Sequential(nn.Linear(in_channels, out_channels))
+        self.proj_skip = nn.Sequential(nn.Linear(skip_channels, out_channels))
+        if norm_layer is not None:
+            self.proj.append(norm_layer(out_channels)); self.proj_skip.append(norm_layer(out_channels))
+        if act_layer is not None:
+            self.proj.append(act_layer()); self.proj_skip.append(act_layer())
+
+    def forward(self, x, skip, coarse_level):
+        """returns (parent.feat, parent.sparse_conv_feat.features)"""
+        skip = self.proj_skip(skip)
+        return SF.unpool_add(skip, self.proj(x), coarse_level), skip
+
+
+class _Stem(nn.Module):
+    pass
+
+
+class Embedding(PointModule):
+    def __init__(self, in_channels, embed_channels, norm_layer=None, act_layer=None):
+        super().__init__()
+        self.in_channels, self.embed_channels = in_channels, embed_channels
+        self.stem = _Stem()
+        self.stem.conv = SubMConv3d(in_channels, embed_channels, 5, bias=False, indice_key="stem")
+        if norm_layer is not None:
+            self.stem.norm = norm_layer(embed_channels)
+        if act_layer is not None:
+            self.stem.act = act_layer()
+
+    def forward(self, feat, level):
+        x = self.stem.conv(feat, level)
+        if hasattr(self.stem, "norm"):
+            x = self.stem.norm(x)
+        if hasattr(self.stem, "act"):
+            x = self.stem.act(x)
+        return x
+
+
+class _Stage(nn.Module):
+    pass
+
+
+@MODELS.register_module("PT-v3m1")
+class PointTransformerV3(PointModule):
+    def __init__(self, in_channels=6, order=("z", "z-trans"), stride=(2, 2, 2, 2), enc_depths=(2, 2, 2, 6, 2),
+                 enc_channels=(32, 64, 128, 256, 512), enc_num_head=(2, 4, 8, 16, 32),
+                 enc_patch_size=(48, 48, 48, 48, 48), dec_depths=(2, 2, 2, 2), dec_channels=(64, 64, 128, 256),
+                 dec_num_head=(4, 4, 8, 16), dec_patch_size=(48, 48, 48, 48), mlp_ratio=4, qkv_bias=True,
+                 qk_scale=None, attn_drop=0.0, proj_drop=0.0, drop_path=0.3, pre_norm=True, shuffle_orders=True,
+                 enable_rpe=False, enable_flash=True, upcast_attention=False, upcast_softmax=False, cls_mode=False,
+                 pdnorm_bn=False, pdnorm_ln=False, pdnorm_decouple=True, pdnorm_adaptive=False, pdnorm_affine=True,
+                 pdnorm_conditions=("ScanNet", "S3DIS", "Structured3D")):
+        super().__init__()
+        if pdnorm_bn or pdnorm_ln:
+            raise NotImplementedError("PDNorm is off in every SceneSplat language config; not on the HIP path")
+        self.num_stages = len(enc_depths)
+        self.order = [order] if isinstance(order, str) else list(order)
+        self.cls_mode, self.shuffle_orders = cls_mode, shuffle_orders
+        self.stride = tuple(stride)
+        assert self.num_stages == len(stride) + 1 == len(enc_channels) == len(enc_num_head) == len(enc_patch_size)
+        assert cls_mode or self.num_stages == len(dec_depths) + 1 == len(dec_channels) + 1
+        assert cls_mode or self.num_stages == len(dec_num_head) + 1 == len(dec_patch_size) + 1
+
+        def bn_layer(c):
+            return nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)
+
+        ln_layer, act_layer = nn.LayerNorm, nn.GELU
+        self.embedding = Embedding(in_channels, enc_channels[0], bn_layer, act_layer)
+        blk = dict(mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=proj_drop,
+                   norm_layer=ln_layer, act_layer=act_layer, pre_norm=pre_norm, enable_rpe=enable_rpe,
+                   enable_flash=enable_flash, upcast_attention=upcast_attention, upcast_softmax=upcast_softmax)
+        enc_dp = [x.item() for x in torch.linspace(0, drop_path, sum(enc_depths))]
+        self.enc = _Stage()
+        for s in range(self.num_stages):
+            dp = enc_dp[sum(enc_depths[:s]):sum(enc_depths[:s + 1])]
+            enc = _Stage()
+            if s > 0:
+                enc.down = SerializedPooling(enc_channels[s - 1], enc_channels[s], stride[s - 1], bn_layer, act_layer)
+            for i in range(enc_depths[s]):
+                setattr(enc, f"block{i}", Block(enc_channels[s], enc_num_head[s], enc_patch_size[s], drop_path=dp[i],
+                                               order_index=i % len(self.order), cpe_indice_key=f"stage{s}", **blk))
+            setattr(self.enc, f"enc{s}", enc)
+        self.enc_depths, self.dec_depths = tuple(enc_depths), tuple(dec_depths)
+        if not cls_mode:
+            dec_dp = [x.item() for x in torch.linspace(0, drop_path, sum(dec_depths))]
+            self.dec = _Stage()
+            dec_channels = list(dec_channels) + [enc_channels[-1]]
+            for s in reversed(range(self.num_stages - 1)):
+                dp = dec_dp[sum(dec_depths[:s]):sum(dec_depths[:s + 1])]
+                dp.reverse()
+                dec = _Stage()
+                dec.up = SerializedUnpooling(dec_channels[s + 1], enc_channels[s], dec_channels[s], bn_layer, act_layer)
+                for i in range(dec_depths[s]):
+                    setattr(dec, f"block{i}", Block(dec_channels[s], dec_num_head[s], dec_patch_size[s], drop_path=dp[i],
+                                                   order_index=i % len(self.order), cpe_indice_key=f"stage{s}", **blk))
+                setattr(self.dec, f"dec{s}", dec)
+
+    def draw_perms(self):
+        """Curve-order permutations for one forward, drawn from the CPU RNG like the reference:
+        level 0 only when shuffle_orders (structure.py:94-98), every pooled level always
+        (SerializedPooling.shuffle_orders defaults to True and is never overridden)."""
+        K = len(self.order)
+        perms = [torch.randperm(K).tolist() if self.shuffle_orders else list(range(K))]
+        for s in range(1, self.num_stages):
+            down = getattr(self.enc, f"enc{s}").down
+            perms.append(torch.randperm(K).tolist() if down.shuffle_orders else list(range(K)))
+        return perms
+
+    def forward(self, data_dict, perms=None):
+        point = data_dict if isinstance(data_dict, Point) else Point(data_dict)
+        feat = point["feat"]
+        if not feat.is_cuda:
+            raise RuntimeError("PT-v3m1 (scenesplat_amd) runs on the GPU only: the HIP path has no CPU fallback")
+        if "grid_coord" not in point:
+            if not {"grid_size", "coord"} <= set(point.keys()):
+                raise KeyError("need grid_coord, or coord + grid_size (structure.py:54-62)")
+            c = point["coord"]
+            point["grid_coord"] = torch.div(c - c.min(0)[0], point["grid_size"], rounding_mode="trunc").int()
+        if dict.__contains__(point, "offset"):
+            offset = point["offset"]
+        else:
+            offset = point["offset"]  # derived lazily from batch
+        plan = build_plan(point["grid_coord"], offset, self.order, self.stride,
+                          perms if perms is not None else self.draw_perms())
+        levels = plan.levels
+        x = self.embedding(feat, levels[0])
+        skips = []
+        for s in range(self.num_stages):
+            enc = getattr(self.enc, f"enc{s}")
+            if s > 0:
+                skips.append(x)
+                x = enc.down(x, levels[s])
+            for i in range(self.enc_depths[s]):
+                x = getattr(enc, f"block{i}")(x, x, levels[s])
+        lv = self.num_stages - 1
+        if not self.cls_mode:
+            for s in reversed(range(self.num_stages - 1)):
+                dec = getattr(self.dec, f"dec{s}")
+                x, conv_in = dec.up(x, skips[s], levels[s + 1])
+                for i in range(self.dec_depths[s]):
+                    x = getattr(dec, f"block{i}")(x, conv_in if i == 0 else x, levels[s])
+            lv = 0
+        out = Point(feat=x, plan=plan, level=lv)
+        for k in ("coord", "grid_coord", "offset"):
+            if lv == 0 and dict.__contains__(point, k):
+                out[k] = point[k]
+        return out

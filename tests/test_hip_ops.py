@@ -1,0 +1,160 @@
+"""GPU parity: float kernels (rows, CSR pooling, submanifold conv, window attention) vs the
+oracle and the reference golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ops as oops
+from oracle import ptv3 as optv3
+
+pytestmark = pytest.mark.gpu
+ORD = ("z", "z-trans", "hilbert", "hilbert-trans")
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+@pytest.mark.parametrize("C,dtype", [(11, torch.float32), (32, torch.float32), (768, torch.bfloat16), (6, torch.bfloat16)])
+def test_gather_scatter_rows(C, dtype):
+    from scenesplat_amd import native as nv
+    g = torch.Generator().manual_seed(C)
+    src = torch.randn(1000, C, generator=g).to(dtype).cuda()
+    idx = torch.randint(-1, 1000, (1777,), generator=g, dtype=torch.int32).cuda()
+    out = nv.gather_rows(src, idx)
+    ref = torch.where((idx >= 0).unsqueeze(1), src[idx.clamp(min=0).long()], torch.zeros_like(src[:1]))
+    assert torch.equal(out, ref)
+    perm = torch.randperm(1000, generator=g).to(torch.int32).cuda()
+    perm[::7] = -1
+    dst = torch.zeros_like(src)
+    nv.scatter_rows(src, perm, dst)
+    ref = torch.zeros_like(src)
+    keep = perm >= 0
+    ref[perm[keep].long()] = src[keep]
+    assert torch.equal(dst, ref)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
+def test_segment_mean_and_unpool_against_oracle(dtype, tol):
+    from scenesplat_amd import functional as SF
+    from scenesplat_amd.plan import build_plan
+    g = torch.Generator().manual_seed(1)
+    gc = torch.randint(0, 40, (5000, 3), generator=g)
+    gc = torch.unique(gc, dim=0)
+    gc = gc[torch.randperm(len(gc), generator=g)]
+    offs = torch.tensor([len(gc) // 2, len(gc)])
+    plan = build_plan(gc.cuda(), offs.cuda(), ORD, (2,))
+    ref = optv3.build_levels(gc.numpy(), offs.numpy(), ORD, (2,))
+    fine, coarse = plan.levels
+    C = 24
+    x = torch.randn(fine.n, C, generator=g)
+    up = torch.randn(coarse.n, C, generator=g)
+    xg = x.to(dtype).cuda().requires_grad_(True)
+    y = SF.segment_mean(xg, coarse)
+    xo = x.clone().requires_grad_(True)
+    yo = oops.segment_csr(xo[torch.as_tensor(ref[1].indices)], ref[1].idx_ptr, "mean")
+    assert torch.allclose(y.float().cpu(), yo, atol=tol, rtol=tol)
+    cot = torch.randn(coarse.n, C, generator=g)
+    (y.float() * cot.cuda()).sum().backward(); (yo * cot).sum().backward()
+    assert torch.allclose(xg.grad.float().cpu(), xo.grad, atol=tol, rtol=tol)
+    # unpool
+    sg, ug = x.to(dtype).cuda().requires_grad_(True), up.to(dtype).cuda().requires_grad_(True)
+    z = SF.unpool_add(sg, ug, coarse)
+    so, uo = x.clone().requires_grad_(True), up.clone().requires_grad_(True)
+    zo = so + uo[torch.as_tensor(ref[1].cluster)]
+    assert torch.allclose(z.float().cpu(), zo, atol=tol * 4, rtol=tol)
+    cot = torch.randn(fine.n, C, generator=g)
+    (z.float() * cot.cuda()).sum().backward(); (zo * cot).sum().backward()
+    assert torch.allclose(sg.grad.float().cpu(), so.grad, atol=tol, rtol=tol)
+    assert torch.allclose(ug.grad.float().cpu(), uo.grad, atol=tol * 8, rtol=tol * 2)
+
+
+@pytest.mark.parametrize("k,cin,cout,dup", [(3, 16, 16, False), (5, 11, 32, False), (3, 8, 8, True)])
+def test_subm_conv_against_oracle(k, cin, cout, dup):
+    from scenesplat_amd import functional as SF
+    from scenesplat_amd.plan import build_plan
+    g = torch.Generator().manual_seed(k + cin)
+    gc = torch.randint(0, 12, (1500, 3), generator=g)
+    if not dup:
+        gc = torch.unique(gc, dim=0)
+        gc = gc[torch.randperm(len(gc), generator=g)]
+    n = len(gc)
+    offs = torch.tensor([n // 3, n])
+    plan = build_plan(gc.cuda(), offs.cuda(), ORD, ())
+    lv = plan.levels[0]
+    assert lv.has_duplicates == dup
+    batch = np.repeat([0, 1], [n // 3, n - n // 3])
+    nbr = oops.neighbor_table(gc.numpy(), batch, k)
+    x = torch.randn(n, cin, generator=g); w = torch.randn(cout, k, k, k, cin, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    cot = torch.randn(n, cout, generator=g)
+    xo, wo, bo = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yo = oops.subm_conv3d(xo, wo, bo, nbr)
+    (yo * cot).sum().backward()
+    xg, wg, bg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = SF.subm_conv3d(xg, wg, bg, lv.neighbors(k), lv.has_duplicates, torch.float32)
+    (y * cot.cuda()).sum().backward()
+    assert torch.allclose(y.cpu(), yo, atol=2e-4, rtol=1e-4)
+    assert torch.allclose(xg.grad.cpu(), xo.grad, atol=2e-4, rtol=1e-4)
+    assert torch.allclose(wg.grad.cpu(), wo.grad, atol=1e-3, rtol=1e-4)
+    assert torch.allclose(bg.grad.cpu(), bo.grad, atol=1e-3, rtol=1e-4)
+
+
+def _attn_case(golden_dir, name):
+    fx = np.load(os.path.join(golden_dir, "attention.npz"))
+    C, H, K, oi = [int(v) for v in fx[f"{name}_cfg"]]
+    sd = {k[len(name) + 4:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith(name + "_sd_")}
+    return fx, C, H, K, oi, sd
+
+
+@pytest.mark.parametrize("name", ["h2d16", "h2d48"])
+@pytest.mark.parametrize("impl,dtype,tol", [("simt", torch.float32, 3e-5), ("simt", torch.bfloat16, 3e-2)])
+def test_window_attention_matches_reference_module(golden_dir, name, impl, dtype, tol):
+    """SerializedAttention (qkv Linear -> windows -> proj Linear) against the reference module's
+    output and gradients (non-flash math, padded tail window)."""
+    from scenesplat_amd import functional as SF, native as nv
+    from scenesplat_amd.plan import build_plan
+    fx, C, H, K, oi, sd = _attn_case(golden_dir, name)
+    plan = build_plan(dev(fx[f"{name}_gc"]), dev(fx[f"{name}_offset"]), ORD, ())
+    win = plan.levels[0].window(oi, K)
+    assert win.n_pad > win.n            # the fixture exercises duplicate padding
+    x = dev(fx[f"{name}_x"]).requires_grad_(True)
+    p = {k: v.cuda().requires_grad_(True) for k, v in sd.items()}
+    qkv = F.linear(x, p["qkv.weight"], p["qkv.bias"])
+    a = SF.window_attention(qkv.to(dtype), win, H, (C // H) ** -0.5, nv.ATTN_SIMT if impl == "simt" else nv.ATTN_MFMA)
+    y = F.linear(a.float(), p["proj.weight"], p["proj.bias"])
+    (y * dev(fx[f"{name}_cot"])).sum().backward()
+    ref_y = torch.from_numpy(fx[f"{name}_y"])
+    scale = ref_y.abs().max().item()
+    assert (y.detach().cpu() - ref_y).abs().max() <= tol * max(1.0, scale)
+    ref_dx = torch.from_numpy(fx[f"{name}_dx"])
+    assert (x.grad.cpu() - ref_dx).abs().max() <= tol * max(1.0, ref_dx.abs().max().item()) * 2
+    for k in p:
+        r = torch.from_numpy(fx[f"{name}_grad_{k}"])
+        assert (p[k].grad.cpu() - r).norm() <= tol * 4 * r.norm() + 1e-5, k
+
+
+@pytest.mark.parametrize("L", [1, 5, 63, 64, 65, 200])
+def test_window_attention_short_windows(L):
+    """An element with <= K points is one short window (varlen semantics, ptv3:135-136)."""
+    from scenesplat_amd import functional as SF, native as nv
+    from scenesplat_amd.plan import build_plan
+    g = torch.Generator().manual_seed(L)
+    n = L + 300
+    gc = torch.stack([torch.randperm(n, generator=g), torch.zeros(n, dtype=torch.long), torch.zeros(n, dtype=torch.long)], 1)
+    offs = torch.tensor([L, n])
+    plan = build_plan(gc.cuda(), offs.cuda(), ("hilbert",), ())
+    lv = plan.levels[0]
+    win = lv.window(0, 256)
+    H, d = 2, 16
+    qkv = torch.randn(n, 3 * H * d, generator=g)
+    out = SF.window_attention(qkv.cuda(), win, H, d ** -0.5, nv.ATTN_SIMT).cpu()
+    ref = optv3.build_levels(gc.numpy(), offs.numpy(), ("hilbert",), ())[0]
+    pad, unpad, cu = ref.padding(256)
+    o = oops.window_attention(qkv[torch.as_tensor(ref.order[0][pad])], cu, H, d ** -0.5)
+    o = o[torch.as_tensor(unpad[ref.inverse[0]])]
+    assert torch.allclose(out, o, atol=2e-5, rtol=1e-4)
