@@ -140,8 +140,13 @@ def main():
             out = net(dict(feat=data["feat"], grid_coord=data["grid_coord"], offset=data["offset"]))
         (out.feat.float() * cot).sum().backward()
 
-    for _ in range(args.warmup):
-        step()
+    def log(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    for i in range(args.warmup):
+        t_ = time.perf_counter(); step(); torch.cuda.synchronize()
+        log("warmup step %d: %.1f ms" % (i, (time.perf_counter() - t_) * 1e3))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -170,8 +175,10 @@ def main():
                        "gaussians_per_chunk": n, "chunks_per_gpu": 1,
                        "parallelism": "dp%d" % world, "attention_kernel": "mfma" if impl == nv.ATTN_MFMA else "simt"},
         }
+        log("timed %d steps: %.1f ms/step" % (args.steps, dt / args.steps * 1e3))
         if world == 1:
             attn, hbm = roofline_probes(model, data, impl)
+            log("roofline probes done")
             res["roofline"] = attn
             res["roofline_hbm"] = hbm
             if not args.no_cpu_baseline:

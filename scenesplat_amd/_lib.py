@@ -4,6 +4,11 @@ Loading fails loudly: there is no CPU fallback behind these symbols."""
 import ctypes
 import os
 
+# torch first: PyTorch-ROCm ships its own libamdhip64; it must be the HIP runtime of the process
+# before this library (linked against the same soname) is mapped, or kernels and streams would
+# belong to two different runtimes and every launch fails.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libscenesplat_hip.so")
 

@@ -16,6 +16,8 @@ extern "C" int ss_window_attn_fwd(const void* qkv, const int32_t* gidx, const in
   if (num_windows == 0) return SS_OK;
   if (impl == SS_ATTN_SIMT)
     return ss_attn_fwd_simt(qkv, gidx, sidx, win_start, num_windows, out, lse, channels, num_heads, scale, dtype, stream);
+  if (impl == SS_ATTN_MFMA && dtype == SS_BF16)
+    return ss_attn_fwd_mfma(qkv, gidx, sidx, win_start, num_windows, max_window, out, lse, channels, num_heads, scale, stream);
   return SS_ERR_ARG;
 }
 
@@ -40,6 +42,9 @@ extern "C" int ss_window_attn_bwd(const void* qkv, const void* out, const void* 
   if (impl == SS_ATTN_SIMT)
     rc = ss_attn_bwd_simt(qkv, dout, lse, delta, gidx, sidx, win_start, num_windows, dqkv, extra, channels, num_heads,
                           scale, dtype, stream);
+  else if (impl == SS_ATTN_MFMA && dtype == SS_BF16)
+    rc = ss_attn_bwd_mfma(qkv, dout, lse, delta, gidx, sidx, win_start, num_windows, max_window, dqkv, extra, channels,
+                          num_heads, scale, stream);
   else
     return SS_ERR_ARG;
   if (rc) return rc;

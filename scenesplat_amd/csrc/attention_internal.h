@@ -9,3 +9,8 @@ int ss_attn_fix_borrowed(const int32_t* gidx, const int32_t* sidx, int64_t n_pad
 int ss_attn_bwd_simt(const void* qkv, const void* dout, const float* lse, const float* delta, const int32_t* gidx,
                      const int32_t* sidx, const int32_t* win_start, int W, void* dqkv, void* extra, int C, int H,
                      float scale, int dtype, hipStream_t st);
+int ss_attn_fwd_mfma(const void* qkv, const int32_t* gidx, const int32_t* sidx, const int32_t* win_start, int W,
+                     int max_window, void* out, float* lse, int C, int H, float scale, hipStream_t st);
+int ss_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const float* delta, const int32_t* gidx,
+                     const int32_t* sidx, const int32_t* win_start, int W, int max_window, void* dqkv, void* extra,
+                     int C, int H, float scale, hipStream_t st);

@@ -1,0 +1,615 @@
+// Serialized-window attention on the gfx950 matrix cores (impl = SS_ATTN_MFMA), bf16 in /
+// fp32 accumulate, flash-style (scores never leave registers).  Replaces
+// flash_attn_varlen_qkvpacked_func AND the qkv[order] / feat[inverse] row gathers around it
+// (ptv3:184-216): rows are fetched through gidx and written through sidx inside the kernels.
+//
+// MFMA shape: v_mfma_f32_16x16x32_bf16 everywhere.
+//   forward   S^T = K Q^T (key rows, query on the lane)  -> online softmax lane-local per query
+//             O^T = V^T P^T: P^T is taken straight from the S^T accumulators as the B operand
+//             (the k index inside a 32-key step is permuted identically for A = V^T, which is read
+//             from the row-major V tile with ds_read_b64_tr_b16), so P never touches LDS.
+//   backward  two kernels, no atomics: dQ (query-stationary, same structure as forward) and
+//             dK/dV (key-stationary: keys on the lane, Q/dO tiles streamed through LDS).
+// Head dims 16/32/48/64: the QK^T contraction is zero-padded to 32/64, the PV side uses D/16
+// exact 16-wide tiles (d = 48 = 3 tiles: no padding waste there).
+// LDS images: "row" images ([row][DP] bf16, XOR-swizzled 16-B chunks, conflict-free
+// ds_read_b128) and "tr" images ([row][D] plain, for the transposed reads).
+#include "attention_internal.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
+typedef __attribute__((ext_vector_type(4))) short s4_t;
+typedef __attribute__((ext_vector_type(8))) short s8_t;
+typedef __attribute__((address_space(3))) s4_t lds_s4_t;
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+template <int D> struct ACfg {
+  static constexpr int DP = (D <= 32) ? 32 : 64;   // padded contraction width of QK^T / dO V^T
+  static constexpr int NKS = DP / 32;              // 32-wide k steps over d
+  static constexpr int NDT = D / 16;               // 16-wide d tiles
+  static constexpr int CH = D / 8;                 // 16-byte chunks per global row
+  static constexpr int CHP = DP / 8;               // 16-byte chunks per padded LDS row
+  static constexpr int ROWB = DP * 2;              // bytes per row of a "row" image
+  static constexpr int TRB = D * 2;                // bytes per row of a "tr" image
+};
+
+template <int D> __device__ __forceinline__ int row_img_off(int row, int chunk) {
+  if (ACfg<D>::DP == 64) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+  return row * 64 + ((chunk ^ ((3 * (row >> 2)) & 3)) << 4);
+}
+
+__device__ __forceinline__ bf8_t as_bf8(uint4 v) { return __builtin_bit_cast(bf8_t, v); }
+__device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ bf8_t lds_b128(const char* base, int off) {
+  return as_bf8(*reinterpret_cast<const uint4*>(base + off));
+}
+// transposed read: lane i of each 16-lane group receives column i of a 4-row x 16-col block;
+// lane 4q+p supplies the address of (row q, cols 4p..4p+3)
+__device__ __forceinline__ s4_t lds_tr(const char* addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(addr));
+}
+__device__ __forceinline__ bf8_t cat_tr(s4_t lo, s4_t hi) {
+  s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf8_t, v);
+}
+// 8 f32 -> bf16x8 operand: elements 0..3 from a, 4..7 from b
+__device__ __forceinline__ bf8_t pack8(f32x4_t a, f32x4_t b) {
+  uint4 v;
+  v.x = pack_bf16x2(a[0], a[1]); v.y = pack_bf16x2(a[2], a[3]);
+  v.z = pack_bf16x2(b[0], b[1]); v.w = pack_bf16x2(b[2], b[3]);
+  return as_bf8(v);
+}
+__device__ __forceinline__ float xmax4(float v) {   // max over the 4 lane groups (lanes l, l^16, l^32, l^48)
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xsum4(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ int xcd_remap(int bid, int nb) {   // bijective: blocks sharing an XCD get adjacent logical ids
+  int q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, slot = bid >> 3;
+  return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+}
+
+#define FA_THREADS 256
+#define FA_BQ 256
+#define FA_BK 64
+
+// stage a 64-row K/V tile (rows gidx[p0+r0 .. +63], column block `colofs`) into registers
+template <int D, int NLD>
+__device__ __forceinline__ void tile_load(uint4 (&reg)[NLD], const unsigned short* __restrict__ qkv,
+                                          const int32_t* __restrict__ gidx, int p0, int r0, int L, int64_t C3,
+                                          int colofs_a, int colofs_b, int tid) {
+  constexpr int CH = ACfg<D>::CH;
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    int c = i * FA_THREADS + tid;
+    int second = c >= 64 * CH;
+    int cc = second ? c - 64 * CH : c;
+    int r = cc / CH, ch = cc - r * CH;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < L) {
+      int64_t row = gidx[p0 + r0 + r];
+      v = ld16(qkv + row * C3 + (second ? colofs_b : colofs_a) + ch * 8);
+    }
+    reg[i] = v;
+  }
+}
+
+// =====================================================================================
+// forward
+// =====================================================================================
+template <int D>
+__global__ void __launch_bounds__(FA_THREADS, (D <= 32 ? 2 : 1))
+k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restrict__ gidx,
+                const int32_t* __restrict__ sidx, const int32_t* __restrict__ win_start,
+                unsigned short* __restrict__ out, float* __restrict__ lse, int C, int H, float scale, int qchunks) {
+  using A = ACfg<D>;
+  constexpr int NLD = (2 * 64 * A::CH) / FA_THREADS;     // 16-B loads per thread per K+V tile
+  constexpr int KIMG = 64 * A::ROWB, VIMG = 64 * A::TRB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (KIMG + VIMG)];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, g = lane >> 4;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qc = lid % qchunks; const int t_ = lid / qchunks; const int h = t_ % H; const int w = t_ / H;
+  const int p0 = win_start[w], L = win_start[w + 1] - p0;
+  const int q0 = qc * FA_BQ;
+  if (q0 >= L) return;
+  const int64_t C3 = 3 * (int64_t)C;
+  const float c2 = scale * 1.44269504088896340736f;
+  auto Kbuf = [&](int b_) { return smem + b_ * (KIMG + VIMG); };
+  auto Vbuf = [&](int b_) { return smem + b_ * (KIMG + VIMG) + KIMG; };
+  // zero the contraction padding of the K images once (chunks CH..CHP-1)
+  if (A::CHP > A::CH) {
+    for (int e = tid; e < 2 * 64 * (A::CHP - A::CH); e += FA_THREADS) {
+      int b = e / (64 * (A::CHP - A::CH)); int r = (e / (A::CHP - A::CH)) % 64; int ch = A::CH + e % (A::CHP - A::CH);
+      *reinterpret_cast<uint4*>(Kbuf(b) + row_img_off<D>(r, ch)) = make_uint4(0, 0, 0, 0);
+    }
+  }
+  // Q fragments (B operand of S^T = K Q^T): lane holds Q[q = lq][d = 32ks + 8g .. +7]
+  bf8_t qf[4][A::NKS];
+  int qslot[4];
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    int slot = q0 + wave * 64 + qt * 16 + lq;
+    qslot[qt] = slot;
+    int64_t row = slot < L ? gidx[p0 + slot] : -1;
+#pragma unroll
+    for (int ks = 0; ks < A::NKS; ++ks) {
+      int d0 = 32 * ks + 8 * g;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row >= 0 && d0 < D) v = ld16(qkv + row * C3 + h * D + d0);
+      qf[qt][ks] = as_bf8(v);
+    }
+  }
+  float m[4], l[4];
+  f32x4_t o[A::NDT][4];
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    m[qt] = -1e30f; l[qt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < A::NDT; ++dt) o[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  uint4 stage[NLD];
+  auto stage_write = [&](int b) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      int c = i * FA_THREADS + tid;
+      int second = c >= 64 * A::CH;
+      int cc = second ? c - 64 * A::CH : c;
+      int r = cc / A::CH, ch = cc - r * A::CH;
+      if (second) *reinterpret_cast<uint4*>(Vbuf(b) + r * A::TRB + ch * 16) = stage[i];
+      else *reinterpret_cast<uint4*>(Kbuf(b) + row_img_off<D>(r, ch)) = stage[i];
+    }
+  };
+  tile_load<D, NLD>(stage, qkv, gidx, p0, 0, L, C3, C + h * D, 2 * C + h * D, tid);
+  stage_write(0);
+  __syncthreads();
+  const int ntiles = (L + FA_BK - 1) / FA_BK;
+  for (int t = 0; t < ntiles; ++t) {
+    const int b = t & 1, kv0 = t * FA_BK;
+    if (t + 1 < ntiles) tile_load<D, NLD>(stage, qkv, gidx, p0, kv0 + FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
+    // ---- S^T = K Q^T : s[kt][qt], rows = keys 16kt + 4g + r, col = query lq
+    f32x4_t s[4][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) s[kt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < A::NKS; ++ks) {
+        bf8_t a = lds_b128(Kbuf(b), row_img_off<D>(16 * kt + lq, 4 * ks + g));
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) s[kt][qt] = MFMA16(a, qf[qt][ks], s[kt][qt]);
+      }
+    }
+    if (kv0 + FA_BK > L) {   // mask the keys past the window end (last tile only; wave-uniform)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kv0 + 16 * kt + 4 * g + r >= L) {
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) s[kt][qt][r] = -INFINITY;
+          }
+    }
+    // ---- online softmax, lane-local per query column
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      float mx = s[0][qt][0];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
+      mx = xmax4(mx);
+      float mn = fmaxf(m[qt], mx);
+      float alpha = __builtin_amdgcn_exp2f((m[qt] - mn) * c2);
+      m[qt] = mn;
+      float mc = mn * c2, ps = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], c2, -mc));
+          s[kt][qt][r] = p; ps += p;
+        }
+      l[qt] = l[qt] * alpha + ps;
+#pragma unroll
+      for (int dt = 0; dt < A::NDT; ++dt) o[dt][qt] *= alpha;
+    }
+    // ---- O^T += V^T P^T ; k index (g, j) of step kk <-> key 32kk + 16(j>>2) + 4g + (j&3)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf8_t pf[4];
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) pf[qt] = pack8(s[2 * kk][qt], s[2 * kk + 1][qt]);
+      const char* vbase = Vbuf(b) + (32 * kk + 4 * g + (lq >> 2)) * A::TRB + (lq & 3) * 8;
+#pragma unroll
+      for (int dt = 0; dt < A::NDT; ++dt) {
+        bf8_t vf = cat_tr(lds_tr(vbase + dt * 32), lds_tr(vbase + 16 * A::TRB + dt * 32));
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) o[dt][qt] = MFMA16(vf, pf[qt], o[dt][qt]);
+      }
+    }
+    if (t + 1 < ntiles) stage_write(b ^ 1);
+    __syncthreads();
+  }
+  // ---- epilogue
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    float lt = xsum4(l[qt]);
+    int slot = qslot[qt];
+    if (slot < L) {
+      if (g == 0) lse[(int64_t)(p0 + slot) * H + h] = m[qt] * scale + __logf(lt);
+      int32_t srow = sidx[p0 + slot];
+      if (srow >= 0) {
+        float inv = 1.f / lt;
+        unsigned short* op = out + (int64_t)srow * C + h * D + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < A::NDT; ++dt) {
+          uint2 v;
+          v.x = pack_bf16x2(o[dt][qt][0] * inv, o[dt][qt][1] * inv);
+          v.y = pack_bf16x2(o[dt][qt][2] * inv, o[dt][qt][3] * inv);
+          *reinterpret_cast<uint2*>(op + 16 * dt) = v;
+        }
+      }
+    }
+  }
+}
+
+// =====================================================================================
+// backward, dQ: query-stationary.  S^T and dP^T = V dO^T (key rows, query on the lane),
+// dS^T = P^T o (dP^T - delta_q), dQ^T += K^T dS^T with K^T read transposed from a plain image.
+// =====================================================================================
+template <int D>
+__global__ void __launch_bounds__(FA_THREADS, 1)
+k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ dout,
+                   const float* __restrict__ lse, const float* __restrict__ delta, const int32_t* __restrict__ gidx,
+                   const int32_t* __restrict__ sidx, const int32_t* __restrict__ win_start,
+                   unsigned short* __restrict__ dqkv, int C, int H, float scale, int qchunks) {
+  using A = ACfg<D>;
+  constexpr int NLD = (2 * 64 * A::CH) / FA_THREADS;
+  constexpr int RIMG = 64 * A::ROWB, TIMG = 64 * A::TRB;
+  constexpr int BUF = 2 * RIMG + TIMG;      // K row image, V row image, K tr image
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, g = lane >> 4;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int qc = lid % qchunks; const int t_ = lid / qchunks; const int h = t_ % H; const int w = t_ / H;
+  const int p0 = win_start[w], L = win_start[w + 1] - p0;
+  const int q0 = qc * FA_BQ;
+  if (q0 >= L) return;
+  const int64_t C3 = 3 * (int64_t)C;
+  const float c2 = scale * 1.44269504088896340736f;
+  if (A::CHP > A::CH) {
+    for (int e = tid; e < 4 * 64 * (A::CHP - A::CH); e += FA_THREADS) {
+      int img = e / (64 * (A::CHP - A::CH)); int r = (e / (A::CHP - A::CH)) % 64; int ch = A::CH + e % (A::CHP - A::CH);
+      char* base = smem + (img >> 1) * BUF + (img & 1) * RIMG;
+      *reinterpret_cast<uint4*>(base + row_img_off<D>(r, ch)) = make_uint4(0, 0, 0, 0);
+    }
+  }
+  bf8_t qf[4][A::NKS], gf[4][A::NKS];
+  float lse2[4], dl[4];
+  int32_t srow[4];
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    int slot = q0 + wave * 64 + qt * 16 + lq;
+    bool ok = slot < L;
+    int64_t row = ok ? gidx[p0 + slot] : -1;
+    srow[qt] = ok ? sidx[p0 + slot] : -1;
+    lse2[qt] = ok ? lse[(int64_t)(p0 + slot) * H + h] * 1.44269504088896340736f : 0.f;
+    dl[qt] = ok ? delta[(int64_t)(p0 + slot) * H + h] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < A::NKS; ++ks) {
+      int d0 = 32 * ks + 8 * g;
+      uint4 v = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0);
+      if (row >= 0 && d0 < D) v = ld16(qkv + row * C3 + h * D + d0);
+      if (srow[qt] >= 0 && d0 < D) u = ld16(dout + (int64_t)srow[qt] * C + h * D + d0);
+      qf[qt][ks] = as_bf8(v); gf[qt][ks] = as_bf8(u);
+    }
+  }
+  f32x4_t dq[A::NDT][4];
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < A::NDT; ++dt) dq[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  uint4 stage[NLD];
+  auto stage_write = [&](int b) {
+    char* base = smem + b * BUF;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      int c = i * FA_THREADS + tid;
+      int second = c >= 64 * A::CH;
+      int cc = second ? c - 64 * A::CH : c;
+      int r = cc / A::CH, ch = cc - r * A::CH;
+      if (second) *reinterpret_cast<uint4*>(base + RIMG + row_img_off<D>(r, ch)) = stage[i];
+      else {
+        *reinterpret_cast<uint4*>(base + row_img_off<D>(r, ch)) = stage[i];
+        *reinterpret_cast<uint4*>(base + 2 * RIMG + r * A::TRB + ch * 16) = stage[i];
+      }
+    }
+  };
+  tile_load<D, NLD>(stage, qkv, gidx, p0, 0, L, C3, C + h * D, 2 * C + h * D, tid);
+  stage_write(0);
+  __syncthreads();
+  const int ntiles = (L + FA_BK - 1) / FA_BK;
+  for (int t = 0; t < ntiles; ++t) {
+    const int b = t & 1, kv0 = t * FA_BK;
+    const char* Kr = smem + b * BUF; const char* Vr = Kr + RIMG; const char* Kt = Kr + 2 * RIMG;
+    if (t + 1 < ntiles) tile_load<D, NLD>(stage, qkv, gidx, p0, kv0 + FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
+    f32x4_t s[4][4], dp[4][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) { s[kt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[kt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ks = 0; ks < A::NKS; ++ks) {
+        int off = row_img_off<D>(16 * kt + lq, 4 * ks + g);
+        bf8_t ka = lds_b128(Kr, off), va = lds_b128(Vr, off);
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+          s[kt][qt] = MFMA16(ka, qf[qt][ks], s[kt][qt]);
+          dp[kt][qt] = MFMA16(va, gf[qt][ks], dp[kt][qt]);
+        }
+      }
+    }
+    const bool tail = kv0 + FA_BK > L;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], c2, -lse2[qt]));
+          float ds = p * (dp[kt][qt][r] - dl[qt]);
+          if (tail && kv0 + 16 * kt + 4 * g + r >= L) ds = 0.f;
+          s[kt][qt][r] = ds;
+        }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf8_t df[4];
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) df[qt] = pack8(s[2 * kk][qt], s[2 * kk + 1][qt]);
+      const char* kbase = Kt + (32 * kk + 4 * g + (lq >> 2)) * A::TRB + (lq & 3) * 8;
+#pragma unroll
+      for (int dt = 0; dt < A::NDT; ++dt) {
+        bf8_t kf = cat_tr(lds_tr(kbase + dt * 32), lds_tr(kbase + 16 * A::TRB + dt * 32));
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) dq[dt][qt] = MFMA16(kf, df[qt], dq[dt][qt]);
+      }
+    }
+    if (t + 1 < ntiles) stage_write(b ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    if (srow[qt] >= 0) {
+      unsigned short* op = dqkv + (int64_t)srow[qt] * C3 + h * D + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < A::NDT; ++dt) {
+        uint2 v;
+        v.x = pack_bf16x2(dq[dt][qt][0] * scale, dq[dt][qt][1] * scale);
+        v.y = pack_bf16x2(dq[dt][qt][2] * scale, dq[dt][qt][3] * scale);
+        *reinterpret_cast<uint2*>(op + 16 * dt) = v;
+      }
+    }
+  }
+}
+
+// =====================================================================================
+// backward, dK/dV: key-stationary.  Each wave owns 64 keys (K, V fragments in registers, key on
+// the lane); 32-query tiles of Q and dO stream through LDS (row image for S / dP, tr image for
+// dV^T += dO^T P and dK^T += Q^T dS).
+// =====================================================================================
+#define FA_BQ2 32
+template <int D>
+__global__ void __launch_bounds__(FA_THREADS, 1)
+k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ dout,
+                    const float* __restrict__ lse, const float* __restrict__ delta, const int32_t* __restrict__ gidx,
+                    const int32_t* __restrict__ sidx, const int32_t* __restrict__ win_start,
+                    unsigned short* __restrict__ dqkv, unsigned short* __restrict__ extra, int C, int H, float scale,
+                    int kchunks) {
+  using A = ACfg<D>;
+  constexpr int TOT = 2 * FA_BQ2 * A::CH;                     // 16-B chunks per (Q, dO) tile
+  constexpr int NLD = (TOT + FA_THREADS - 1) / FA_THREADS;
+  constexpr int RIMG = FA_BQ2 * A::ROWB, TIMG = FA_BQ2 * A::TRB;
+  constexpr int BUF = 2 * RIMG + 2 * TIMG + 2 * FA_BQ2 * 4;   // Q row, dO row, Q tr, dO tr, lse2[32], delta[32]
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, g = lane >> 4;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int kc = lid % kchunks; const int t_ = lid / kchunks; const int h = t_ % H; const int w = t_ / H;
+  const int p0 = win_start[w], L = win_start[w + 1] - p0;
+  const int k0 = kc * 256;
+  if (k0 >= L) return;
+  const int64_t C3 = 3 * (int64_t)C;
+  const float c2 = scale * 1.44269504088896340736f;
+  if (A::CHP > A::CH) {
+    for (int e = tid; e < 4 * FA_BQ2 * (A::CHP - A::CH); e += FA_THREADS) {
+      int img = e / (FA_BQ2 * (A::CHP - A::CH)); int r = (e / (A::CHP - A::CH)) % FA_BQ2; int ch = A::CH + e % (A::CHP - A::CH);
+      char* base = smem + (img >> 1) * BUF + (img & 1) * RIMG;
+      *reinterpret_cast<uint4*>(base + row_img_off<D>(r, ch)) = make_uint4(0, 0, 0, 0);
+    }
+  }
+  // K / V fragments as B operands: lane holds K[key = lq][d = 32ks + 8g ..]
+  bf8_t kf[4][A::NKS], vf[4][A::NKS];
+  int kslot[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    int slot = k0 + wave * 64 + kt * 16 + lq;
+    kslot[kt] = slot;
+    int64_t row = slot < L ? gidx[p0 + slot] : -1;
+#pragma unroll
+    for (int ks = 0; ks < A::NKS; ++ks) {
+      int d0 = 32 * ks + 8 * g;
+      uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
+      if (row >= 0 && d0 < D) { a = ld16(qkv + row * C3 + C + h * D + d0); b = ld16(qkv + row * C3 + 2 * C + h * D + d0); }
+      kf[kt][ks] = as_bf8(a); vf[kt][ks] = as_bf8(b);
+    }
+  }
+  f32x4_t dk[A::NDT][4], dv[A::NDT][4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int dt = 0; dt < A::NDT; ++dt) { dk[dt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  uint4 stage[NLD];
+  float st_l = 0.f, st_d = 0.f;
+  auto stage_load = [&](int qb) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      int c = i * FA_THREADS + tid;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (c < TOT) {
+        int second = c >= FA_BQ2 * A::CH;
+        int cc = second ? c - FA_BQ2 * A::CH : c;
+        int r = cc / A::CH, ch = cc - r * A::CH;
+        if (qb + r < L) {
+          if (!second) v = ld16(qkv + (int64_t)gidx[p0 + qb + r] * C3 + h * D + ch * 8);
+          else { int32_t sr = sidx[p0 + qb + r]; if (sr >= 0) v = ld16(dout + (int64_t)sr * C + h * D + ch * 8); }
+        }
+      }
+      stage[i] = v;
+    }
+    if (tid < FA_BQ2) {
+      bool ok = qb + tid < L;
+      st_l = ok ? lse[(int64_t)(p0 + qb + tid) * H + h] * 1.44269504088896340736f : 1e30f;   // p = 0 for rows past the window
+      st_d = ok ? delta[(int64_t)(p0 + qb + tid) * H + h] : 0.f;
+    }
+  };
+  auto stage_write = [&](int b) {
+    char* base = smem + b * BUF;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      int c = i * FA_THREADS + tid;
+      if (c < TOT) {
+        int second = c >= FA_BQ2 * A::CH;
+        int cc = second ? c - FA_BQ2 * A::CH : c;
+        int r = cc / A::CH, ch = cc - r * A::CH;
+        *reinterpret_cast<uint4*>(base + second * RIMG + row_img_off<D>(r, ch)) = stage[i];
+        *reinterpret_cast<uint4*>(base + 2 * RIMG + second * TIMG + r * A::TRB + ch * 16) = stage[i];
+      }
+    }
+    if (tid < FA_BQ2) {
+      float* f = reinterpret_cast<float*>(base + 2 * RIMG + 2 * TIMG);
+      f[tid] = st_l; f[FA_BQ2 + tid] = st_d;
+    }
+  };
+  stage_load(0);
+  stage_write(0);
+  __syncthreads();
+  const int ntiles = (L + FA_BQ2 - 1) / FA_BQ2;
+  for (int t = 0; t < ntiles; ++t) {
+    const int b = t & 1;
+    const char* Qr = smem + b * BUF; const char* Gr = Qr + RIMG; const char* Qt = Qr + 2 * RIMG; const char* Gt = Qt + TIMG;
+    const float* fl = reinterpret_cast<const float*>(Qr + 2 * RIMG + 2 * TIMG);
+    if (t + 1 < ntiles) stage_load((t + 1) * FA_BQ2);
+    // S[q][key], dP[q][key]: rows = queries 16qt + 4g + r, col = key lq (tile kt)
+    f32x4_t s[2][4], dp[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) { s[qt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[qt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ks = 0; ks < A::NKS; ++ks) {
+        int off = row_img_off<D>(16 * qt + lq, 4 * ks + g);
+        bf8_t qa = lds_b128(Qr, off), ga = lds_b128(Gr, off);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          s[qt][kt] = MFMA16(qa, kf[kt][ks], s[qt][kt]);
+          dp[qt][kt] = MFMA16(ga, vf[kt][ks], dp[qt][kt]);
+        }
+      }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float l2 = fl[16 * qt + 4 * g + r], dd = fl[FA_BQ2 + 16 * qt + 4 * g + r];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][kt][r], c2, -l2));
+          s[qt][kt][r] = p;
+          dp[qt][kt][r] = p * (dp[qt][kt][r] - dd);
+        }
+      }
+    // dV^T += dO^T P ; dK^T += Q^T dS ; k index (g, j) <-> query 16(j>>2) + 4g + (j&3)
+    {
+      const char* gbase = Gt + (4 * g + (lq >> 2)) * A::TRB + (lq & 3) * 8;
+      const char* qbase = Qt + (4 * g + (lq >> 2)) * A::TRB + (lq & 3) * 8;
+      bf8_t pf[4], df[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) { pf[kt] = pack8(s[0][kt], s[1][kt]); df[kt] = pack8(dp[0][kt], dp[1][kt]); }
+#pragma unroll
+      for (int dt = 0; dt < A::NDT; ++dt) {
+        bf8_t ga = cat_tr(lds_tr(gbase + dt * 32), lds_tr(gbase + 16 * A::TRB + dt * 32));
+        bf8_t qa = cat_tr(lds_tr(qbase + dt * 32), lds_tr(qbase + 16 * A::TRB + dt * 32));
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          dv[dt][kt] = MFMA16(ga, pf[kt], dv[dt][kt]);
+          dk[dt][kt] = MFMA16(qa, df[kt], dk[dt][kt]);
+        }
+      }
+    }
+    if (t + 1 < ntiles) stage_write(b ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    int slot = kslot[kt];
+    if (slot < L) {
+      int32_t sr = sidx[p0 + slot];
+      unsigned short* kp; unsigned short* vp;
+      if (sr >= 0) { kp = dqkv + (int64_t)sr * C3 + C + h * D + 4 * g; vp = kp + C; }
+      else { kp = extra + (int64_t)(-1 - sr) * 2 * C + h * D + 4 * g; vp = kp + C; }
+#pragma unroll
+      for (int dt = 0; dt < A::NDT; ++dt) {
+        uint2 a, b2;
+        a.x = pack_bf16x2(dk[dt][kt][0] * scale, dk[dt][kt][1] * scale);
+        a.y = pack_bf16x2(dk[dt][kt][2] * scale, dk[dt][kt][3] * scale);
+        b2.x = pack_bf16x2(dv[dt][kt][0], dv[dt][kt][1]);
+        b2.y = pack_bf16x2(dv[dt][kt][2], dv[dt][kt][3]);
+        *reinterpret_cast<uint2*>(kp + 16 * dt) = a;
+        *reinterpret_cast<uint2*>(vp + 16 * dt) = b2;
+      }
+    }
+  }
+}
+
+// =====================================================================================
+// host launchers
+// =====================================================================================
+int ss_attn_fwd_mfma(const void* qkv, const int32_t* gidx, const int32_t* sidx, const int32_t* win_start, int W,
+                     int max_window, void* out, float* lse, int C, int H, float scale, hipStream_t st) {
+  const int D = C / H;
+  if ((C & 7) || max_window <= 0) return SS_ERR_ARG;
+  const int qchunks = (max_window + FA_BQ - 1) / FA_BQ;
+  dim3 g((unsigned)(W * H * qchunks)), b(FA_THREADS);
+  const unsigned short* q = (const unsigned short*)qkv; unsigned short* o = (unsigned short*)out;
+  switch (D) {
+    case 16: SS_LAUNCH((k_attn_fwd_mfma<16>), g, b, 0, st, q, gidx, sidx, win_start, o, lse, C, H, scale, qchunks); break;
+    case 32: SS_LAUNCH((k_attn_fwd_mfma<32>), g, b, 0, st, q, gidx, sidx, win_start, o, lse, C, H, scale, qchunks); break;
+    case 48: SS_LAUNCH((k_attn_fwd_mfma<48>), g, b, 0, st, q, gidx, sidx, win_start, o, lse, C, H, scale, qchunks); break;
+    case 64: SS_LAUNCH((k_attn_fwd_mfma<64>), g, b, 0, st, q, gidx, sidx, win_start, o, lse, C, H, scale, qchunks); break;
+    default: return SS_ERR_ARG;
+  }
+  return SS_OK;
+}
+
+int ss_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const float* delta, const int32_t* gidx,
+                     const int32_t* sidx, const int32_t* win_start, int W, int max_window, void* dqkv, void* extra,
+                     int C, int H, float scale, hipStream_t st) {
+  const int D = C / H;
+  if ((C & 7) || max_window <= 0) return SS_ERR_ARG;
+  const int chunks = (max_window + 255) / 256;
+  dim3 g((unsigned)(W * H * chunks)), b(FA_THREADS);
+  const unsigned short* q = (const unsigned short*)qkv; const unsigned short* go = (const unsigned short*)dout;
+  unsigned short* dq = (unsigned short*)dqkv; unsigned short* ex = (unsigned short*)extra;
+#define SS_MB_CASE(DD)                                                                                              \
+  case DD:                                                                                                          \
+    SS_LAUNCH((k_attn_bwd_dq_mfma<DD>), g, b, 0, st, q, go, lse, delta, gidx, sidx, win_start, dq, C, H, scale, chunks); \
+    SS_LAUNCH((k_attn_bwd_dkv_mfma<DD>), g, b, 0, st, q, go, lse, delta, gidx, sidx, win_start, dq, ex, C, H, scale, chunks); \
+    break;
+  switch (D) {
+    SS_MB_CASE(16) SS_MB_CASE(32) SS_MB_CASE(48) SS_MB_CASE(64)
+    default: return SS_ERR_ARG;
+  }
+#undef SS_MB_CASE
+  return SS_OK;
+}

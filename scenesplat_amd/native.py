@@ -12,6 +12,7 @@ from ._lib import check
 
 F32, BF16 = 0, 1
 ATTN_SIMT, ATTN_MFMA = 0, 1
+HAVE_MFMA_ATTN = True  # bf16 MFMA window attention (csrc/attention_mfma.hip)
 ORDER_IDS = {"z": 0, "z-trans": 1, "hilbert": 2, "hilbert-trans": 3}
 
 
