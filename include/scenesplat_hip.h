@@ -85,6 +85,16 @@ int ss_subm_rulebook(const int32_t* grid_coord, const int32_t* batch, int64_t n,
                      const int64_t* zkeys_sorted, const int32_t* zorder, int swap_xy, int kernel_size, int32_t* nbr,
                      ss_stream_t stream);
 
+/* bf16 MFMA implicit GEMM.  in (n,cin) bf16; weight (cout,taps,cin) bf16 (the reference's
+ * (Cout,k,k,k,Cin) layout flattened); bias (cout) f32 or NULL; rowperm (n) = site walk order (z-order)
+ * or NULL; out (n,cout) bf16 / f32.  cin % 8 == 0.  dgrad = same call on dout with the tap-mirrored
+ * transposed weight (cin,taps,cout). */
+int ss_subm_conv_fwd(const void* in, const void* weight, const float* bias, const int32_t* nbr, const int32_t* rowperm,
+                     void* out, int64_t n, int cin, int cout, int taps, int out_dtype, ss_stream_t stream);
+/* dweight (cout,taps,cin) f32, ACCUMULATED into (caller zeroes it); cin % 8 == 0, cout % 8 == 0 */
+int ss_subm_conv_wgrad(const void* in, const void* dout, const int32_t* nbr, const int32_t* rowperm, float* dweight,
+                       int64_t n, int cin, int cout, int taps, ss_stream_t stream);
+
 /* ---- row movement ------------------------------------------------------------------------ */
 int ss_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_dst, int64_t row_bytes, ss_stream_t stream);
 int ss_scatter_rows(const void* src, const int32_t* idx, void* dst, int64_t n_src, int64_t row_bytes, ss_stream_t stream);

@@ -1,0 +1,307 @@
+// Submanifold 3-D convolution on a precomputed rulebook, bf16 MFMA implicit GEMM (gfx950).
+// Replaces spconv.SubMConv3d (ptv3:278-284 CPE k=3, ptv3:499-506 stem k=5) forward, dgrad, wgrad.
+//
+//   forward / dgrad   out[i][co] = b[co] + sum_t sum_ci in[nbr[t][i]][ci] * W[co][t][ci]
+//       one kernel (k_subm_gemm).  GEMM view: M = sites, N = Cout, K = taps x Cin; the A tile is
+//       GATHERED through the rulebook while it is staged (128-byte row pieces, zero rows for
+//       missing neighbours), taps with no neighbour in the whole 128-site tile are skipped --
+//       sites are walked in z-order (rowperm) so tiles are spatially compact and on surfaces
+//       roughly two thirds of the taps drop out.  dgrad = the same kernel on dout with the
+//       tap-mirrored, transposed weights (rulebook symmetry nbr[i][t]=j <=> nbr[j][T-1-t]=i).
+//   wgrad             dW[co][t][ci] = sum_i dout[i][co] * in[nbr[t][i]][ci]
+//       k_subm_wgrad: M = Cout, N = Cin, K = sites (split across workgroups, fp32 atomics into a
+//       zeroed dW); both operands are [k][m]-major, so fragments come from plain LDS images via
+//       ds_read_b64_tr_b16 with the same k permutation on both sides.
+// MFMA: v_mfma_f32_16x16x32_bf16, 128x128 workgroup tile, 4 waves (2x2) of 64x64, BK = 64.
+#include "common.h"
+#include "../../include/scenesplat_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
+typedef __attribute__((ext_vector_type(4))) short s4_t;
+typedef __attribute__((ext_vector_type(8))) short s8_t;
+typedef __attribute__((address_space(3))) s4_t lds_s4_t;
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+#define CV_THREADS 256
+#define CV_BM 128
+#define CV_BN 128
+#define CV_BK 64
+#define CV_TG 27   // taps per rulebook group held in LDS (27 keeps the workgroup under 80 KB: 2 per CU)
+
+__device__ __forceinline__ bf8_t cv_as_bf8(uint4 v) { return __builtin_bit_cast(bf8_t, v); }
+__device__ __forceinline__ int cv_row_off(int row, int chunk) {   // [row][64 bf16] image, 8 chunks of 16 B, XOR swizzle
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+__device__ __forceinline__ bf8_t cv_lds_b128(const char* base, int off) {
+  return cv_as_bf8(*reinterpret_cast<const uint4*>(base + off));
+}
+__device__ __forceinline__ s4_t cv_lds_tr(const char* addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t*)(addr));
+}
+__device__ __forceinline__ bf8_t cv_cat(s4_t lo, s4_t hi) {
+  s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf8_t, v);
+}
+// plain [k][128 cols] bf16 image (256-B rows, 16 chunks), swizzled for conflict-free transposed reads
+__device__ __forceinline__ int cv_tr_off(int row, int chunk) {
+  return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+template <typename OutT>
+__global__ void __launch_bounds__(CV_THREADS, 2)
+k_subm_gemm(const unsigned short* __restrict__ in, const unsigned short* __restrict__ W, const float* __restrict__ bias,
+            const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowperm, OutT* __restrict__ out, int n,
+            int Cin, int Cout, int taps) {
+  constexpr int IMG = CV_BM * CV_BK * 2;   // 16 KB
+  __shared__ __attribute__((aligned(16))) char smem[4 * IMG];            // A0 B0 A1 B1
+  __shared__ int32_t nbr_s[CV_TG][CV_BM];
+  __shared__ int32_t rowid_s[CV_BM];
+  __shared__ int act_s[CV_TG];
+  __shared__ unsigned mask_s;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * CV_BM, n0 = blockIdx.y * CV_BN;
+  if (tid < CV_BM) {
+    int r = m0 + tid;
+    rowid_s[tid] = r < n ? (rowperm ? rowperm[r] : r) : -1;
+  }
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int ksteps = (Cin + CV_BK - 1) / CV_BK;
+  uint4 sa[4], sb[4];
+  auto stage_load = [&](int tt, int tap, int ci0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int c = i * CV_THREADS + tid;
+      int r = c >> 3, ch = c & 7;
+      int ci = ci0 + ch * 8;
+      uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+      int src = nbr_s[tt][r];
+      if (src >= 0 && ci < Cin) va = *reinterpret_cast<const uint4*>(in + (int64_t)src * Cin + ci);
+      int co = n0 + r;
+      if (co < Cout && ci < Cin) vb = *reinterpret_cast<const uint4*>(W + ((int64_t)co * taps + tap) * Cin + ci);
+      sa[i] = va; sb[i] = vb;
+    }
+  };
+  auto stage_write = [&](int b) {
+    char* A = smem + b * 2 * IMG; char* B = A + IMG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int c = i * CV_THREADS + tid;
+      int r = c >> 3, ch = c & 7;
+      *reinterpret_cast<uint4*>(A + cv_row_off(r, ch)) = sa[i];
+      *reinterpret_cast<uint4*>(B + cv_row_off(r, ch)) = sb[i];
+    }
+  };
+  for (int tg = 0; tg < taps; tg += CV_TG) {
+    const int nt = min(CV_TG, taps - tg);
+    __syncthreads();                     // previous group's LDS reads are done
+    if (tid == 0) mask_s = 0u;
+    __syncthreads();
+    for (int e = tid; e < nt * CV_BM; e += CV_THREADS) {
+      int tt = e / CV_BM, r = e - tt * CV_BM;
+      int row = rowid_s[r];
+      int v = row >= 0 ? nbr[(int64_t)(tg + tt) * n + row] : -1;
+      nbr_s[tt][r] = v;
+      if (v >= 0) atomicOr(&mask_s, 1u << tt);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned mk = mask_s; int c = 0;
+      for (int tt = 0; tt < nt; ++tt) if (mk >> tt & 1u) act_s[c++] = tt;
+      mask_s = (unsigned)c;
+    }
+    __syncthreads();
+    const int nact = (int)mask_s;
+    const int iters = nact * ksteps;
+    if (iters == 0) continue;
+    {
+      int tt = act_s[0];
+      stage_load(tt, tg + tt, 0);
+      stage_write(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+      const int b = it & 1;
+      if (it + 1 < iters) {
+        int a_ = (it + 1) / ksteps, k_ = (it + 1) - a_ * ksteps;
+        int tt = act_s[a_];
+        stage_load(tt, tg + tt, k_ * CV_BK);
+      }
+      const char* A = smem + b * 2 * IMG; const char* B = A + IMG;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf8_t af[4], bf[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[mi] = cv_lds_b128(A, cv_row_off(64 * wm + 16 * mi + lq, 4 * ks + g));
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bf[ni] = cv_lds_b128(B, cv_row_off(64 * wn + 16 * ni + lq, 4 * ks + g));
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = MFMA16(af[mi], bf[ni], acc[mi][ni]);
+      }
+      if (it + 1 < iters) stage_write(b ^ 1);
+      __syncthreads();
+    }
+  }
+  // epilogue: acc[mi][ni][r] -> row 64wm + 16mi + 4g + r, col 64wn + 16ni + lq
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    int col = n0 + 64 * wn + 16 * ni + lq;
+    if (col < Cout) {
+      float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int row = rowid_s[64 * wm + 16 * mi + 4 * g + r];
+          if (row >= 0) ElemIO<OutT>::store(out + (int64_t)row * Cout + col, acc[mi][ni][r] + bv);
+        }
+    }
+  }
+}
+
+// dW[co][t][ci] += sum over the sites of this split
+__global__ void __launch_bounds__(CV_THREADS, 2)
+k_subm_wgrad(const unsigned short* __restrict__ in, const unsigned short* __restrict__ dout,
+             const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowperm, float* __restrict__ dW, int n, int Cin,
+             int Cout, int taps, int ntiles_n, int sites_per_split) {
+  constexpr int IMG = 64 * 256;   // 64 sites x 128 cols bf16 = 16 KB
+  __shared__ __attribute__((aligned(16))) char smem[4 * IMG];   // A0 B0 A1 B1
+  __shared__ int32_t isite_s[2][64], jsite_s[2][64];
+  __shared__ int any_s[2];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = (blockIdx.x / ntiles_n) * 128, n0 = (blockIdx.x % ntiles_n) * 128;
+  const int tap = blockIdx.y;
+  const int kbeg = blockIdx.z * sites_per_split, kend = min(n, kbeg + sites_per_split);
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  uint4 sa[4], sb[4];
+  auto index_load = [&](int b, int k0) {      // wave 0: site ids of the block + "any neighbour" flag
+    if (tid < 64) {
+      int k = k0 + tid;
+      int i = k < kend ? (rowperm ? rowperm[k] : k) : -1;
+      int j = i >= 0 ? nbr[(int64_t)tap * n + i] : -1;
+      isite_s[b][tid] = i; jsite_s[b][tid] = j;
+      unsigned long long m = __ballot(j >= 0);
+      if (tid == 0) any_s[b] = m != 0ULL;
+    }
+  };
+  auto stage_load = [&](int b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int c = i * CV_THREADS + tid;
+      int r = c >> 4, ch = c & 15;
+      uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+      int si = isite_s[b][r], sj = jsite_s[b][r];
+      int co = m0 + ch * 8, ci = n0 + ch * 8;
+      if (sj >= 0) {
+        if (co < Cout) va = *reinterpret_cast<const uint4*>(dout + (int64_t)si * Cout + co);
+        if (ci < Cin) vb = *reinterpret_cast<const uint4*>(in + (int64_t)sj * Cin + ci);
+      }
+      sa[i] = va; sb[i] = vb;
+    }
+  };
+  auto stage_write = [&](int b) {
+    char* A = smem + b * 2 * IMG; char* B = A + IMG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int c = i * CV_THREADS + tid;
+      int r = c >> 4, ch = c & 15;
+      *reinterpret_cast<uint4*>(A + cv_tr_off(r, ch)) = sa[i];
+      *reinterpret_cast<uint4*>(B + cv_tr_off(r, ch)) = sb[i];
+    }
+  };
+  const int nblk = (kend - kbeg + 63) / 64;
+  if (nblk <= 0) return;
+  index_load(0, kbeg);
+  __syncthreads();
+  if (any_s[0]) { stage_load(0); stage_write(0); }
+  if (nblk > 1) index_load(1, kbeg + 64);
+  __syncthreads();
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int b = blk & 1;
+    const bool have_next = blk + 1 < nblk;
+    const bool next_any = have_next && any_s[b ^ 1];
+    if (next_any) stage_load(b ^ 1);
+    if (any_s[b]) {
+      const char* A = smem + b * 2 * IMG; const char* B = A + IMG;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf8_t af[4], bf[4];
+        const int r0 = 32 * kk + 4 * g + (lq >> 2);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          int ch = (64 * wm + 16 * mi) / 8 + ((lq & 3) >> 1);
+          af[mi] = cv_cat(cv_lds_tr(A + cv_tr_off(r0, ch) + 8 * (lq & 1)), cv_lds_tr(A + cv_tr_off(r0 + 16, ch) + 8 * (lq & 1)));
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          int ch = (64 * wn + 16 * ni) / 8 + ((lq & 3) >> 1);
+          bf[ni] = cv_cat(cv_lds_tr(B + cv_tr_off(r0, ch) + 8 * (lq & 1)), cv_lds_tr(B + cv_tr_off(r0 + 16, ch) + 8 * (lq & 1)));
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = MFMA16(af[mi], bf[ni], acc[mi][ni]);
+      }
+    }
+    __syncthreads();                    // all reads of buffer b and of index slot b are done
+    if (next_any) stage_write(b ^ 1);
+    if (blk + 2 < nblk) index_load(b, kbeg + (blk + 2) * 64);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int co = m0 + 64 * wm + 16 * mi + 4 * g + r;
+      if (co < Cout) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          int ci = n0 + 64 * wn + 16 * ni + lq;
+          if (ci < Cin) atomicAdd(dW + ((int64_t)co * taps + tap) * Cin + ci, acc[mi][ni][r]);
+        }
+      }
+    }
+}
+
+extern "C" int ss_subm_conv_fwd(const void* in, const void* weight, const float* bias, const int32_t* nbr,
+                                const int32_t* rowperm, void* out, int64_t n, int cin, int cout, int taps, int out_dtype,
+                                hipStream_t stream) {
+  if (n < 0 || cin <= 0 || cout <= 0 || taps <= 0 || (cin & 7) || n >= (1LL << 31)) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  dim3 g(ss_div_up(n, CV_BM), ss_div_up(cout, CV_BN)), b(CV_THREADS);
+  const unsigned short* x = (const unsigned short*)in; const unsigned short* w = (const unsigned short*)weight;
+  if (out_dtype == SS_BF16)
+    SS_LAUNCH(k_subm_gemm<unsigned short>, g, b, 0, stream, x, w, bias, nbr, rowperm, (unsigned short*)out, (int)n, cin, cout, taps);
+  else if (out_dtype == SS_F32)
+    SS_LAUNCH(k_subm_gemm<float>, g, b, 0, stream, x, w, bias, nbr, rowperm, (float*)out, (int)n, cin, cout, taps);
+  else return SS_ERR_ARG;
+  return SS_OK;
+}
+
+extern "C" int ss_subm_conv_wgrad(const void* in, const void* dout, const int32_t* nbr, const int32_t* rowperm,
+                                  float* dweight, int64_t n, int cin, int cout, int taps, hipStream_t stream) {
+  if (n < 0 || cin <= 0 || cout <= 0 || taps <= 0 || (cin & 7) || (cout & 7) || n >= (1LL << 31)) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  const int tm = ss_div_up(cout, 128), tn = ss_div_up(cin, 128);
+  int splits = 2048 / (tm * tn * taps);
+  int max_splits = ss_div_up(n, 512);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int sps = ss_div_up(ss_div_up(n, splits), 64) * 64;
+  splits = ss_div_up(n, sps);
+  dim3 g(tm * tn, taps, splits), b(CV_THREADS);
+  SS_LAUNCH(k_subm_wgrad, g, b, 0, stream, (const unsigned short*)in, (const unsigned short*)dout, nbr, rowperm, dweight,
+            (int)n, cin, cout, taps, tn, sps);
+  return SS_OK;
+}

@@ -153,6 +153,39 @@ def subm_rulebook(gc32, batch32, depth, zkeys_sorted, zorder, swap_xy, ksize):
     return nbr
 
 
+def subm_conv_fwd(x, w, bias, nbr, rowperm, out_dtype=torch.bfloat16):
+    """x (n,cin) bf16, w (cout,taps,cin) bf16, bias (cout) f32|None, nbr (taps,n) -> (n,cout)."""
+    n, cin = x.shape
+    cout, taps, cin2 = w.shape
+    _req(x, torch.bfloat16, "x"); _req(w, torch.bfloat16, "w"); _req(nbr, torch.int32, "nbr", (taps, n))
+    if cin2 != cin or cin % 8:
+        raise RuntimeError(f"subm_conv_fwd: cin mismatch / not a multiple of 8 ({cin}, {cin2})")
+    if bias is not None:
+        _req(bias, torch.float32, "bias", (cout,))
+    if rowperm is not None:
+        _req(rowperm, torch.int32, "rowperm", (n,))
+    out = torch.empty((n, cout), dtype=out_dtype, device=x.device)
+    check(lib().ss_subm_conv_fwd(_p(x), _p(w), _p(bias), _p(nbr), _p(rowperm), _p(out), n, cin, cout, taps,
+                                 dtype_code(out), _stream()), "ss_subm_conv_fwd")
+    return out
+
+
+def subm_conv_wgrad(x, dout, nbr, rowperm):
+    """-> dW (cout,taps,cin) f32 = sum_i dout[i] (x) x[nbr[t][i]]."""
+    n, cin = x.shape
+    cout = dout.shape[1]
+    taps = nbr.shape[0]
+    _req(x, torch.bfloat16, "x"); _req(dout, torch.bfloat16, "dout", (n, cout)); _req(nbr, torch.int32, "nbr", (taps, n))
+    if cin % 8 or cout % 8:
+        raise RuntimeError("subm_conv_wgrad: channels must be multiples of 8")
+    if rowperm is not None:
+        _req(rowperm, torch.int32, "rowperm", (n,))
+    dw = torch.zeros((cout, taps, cin), dtype=torch.float32, device=x.device)
+    check(lib().ss_subm_conv_wgrad(_p(x), _p(dout), _p(nbr), _p(rowperm), _p(dw), n, cin, cout, taps, _stream()),
+          "ss_subm_conv_wgrad")
+    return dw
+
+
 # ---- rows ------------------------------------------------------------------------------------
 def gather_rows(src, idx, out=None):
     """out[i] = src[idx[i]] (zero row where idx < 0).  src (m, C)."""

@@ -87,6 +87,14 @@ class Level:
             self._windows[key] = w
         return w
 
+    def conv_rowperm(self):
+        """Site walk order of the fused conv kernels: a curve order (z if present) so that a
+        128-site tile is spatially compact (tap skipping, L2 locality)."""
+        for r, name in enumerate(self.curve_names):
+            if name == "z":
+                return self.order[r]
+        return self.order[0]
+
     def neighbors(self, ksize):
         """(k^3, n) int32 tap-major rulebook, shared by every conv of this level (indice_key)."""
         nb = self._nbr.get(ksize)

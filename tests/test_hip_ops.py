@@ -104,6 +104,37 @@ def test_subm_conv_against_oracle(k, cin, cout, dup):
     assert torch.allclose(bg.grad.cpu(), bo.grad, atol=1e-3, rtol=1e-4)
 
 
+@pytest.mark.parametrize("k,cin,cout", [(3, 32, 32), (3, 96, 160), (5, 11, 32), (3, 256, 256), (3, 64, 8)])
+def test_subm_conv_fused_mfma_against_oracle(k, cin, cout):
+    """bf16 MFMA implicit-GEMM conv (fwd, dgrad, wgrad) vs the fp32 oracle on bf16-rounded operands."""
+    from scenesplat_amd import functional as SF
+    from scenesplat_amd.plan import build_plan
+    g = torch.Generator().manual_seed(k * 1000 + cin + cout)
+    gc = torch.unique(torch.randint(0, 14, (2600, 3), generator=g), dim=0)
+    gc = gc[torch.randperm(len(gc), generator=g)]
+    n = len(gc)
+    offs = torch.tensor([n // 3, n])
+    plan = build_plan(gc.cuda(), offs.cuda(), ORD, ())
+    lv = plan.levels[0]
+    batch = np.repeat([0, 1], [n // 3, n - n // 3])
+    nbr = oops.neighbor_table(gc.numpy(), batch, k)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    x = rb(torch.randn(n, cin, generator=g)); w = rb(torch.randn(cout, k, k, k, cin, generator=g) * 0.2)
+    b = torch.randn(cout, generator=g); cot = rb(torch.randn(n, cout, generator=g))
+    xo, wo, bo = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yo = oops.subm_conv3d(xo, wo, bo, nbr)
+    (yo * cot).sum().backward()
+    xg, wg, bg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = SF.subm_conv3d(xg, wg, bg, lv.neighbors(k), False, torch.bfloat16, lv.conv_rowperm())
+    assert y.dtype == torch.bfloat16
+    (y.float() * cot.cuda()).sum().backward()
+    def rel(a, r): return ((a.float().cpu() - r).norm() / r.norm()).item()
+    assert rel(y, yo) < 6e-3, rel(y, yo)                 # bf16 output rounding
+    assert rel(xg.grad, xo.grad) < 6e-3, rel(xg.grad, xo.grad)
+    assert rel(wg.grad, wo.grad) < 2e-3, rel(wg.grad, wo.grad)   # fp32 accumulate / output
+    assert rel(bg.grad, bo.grad) < 2e-3
+
+
 def _attn_case(golden_dir, name):
     fx = np.load(os.path.join(golden_dir, "attention.npz"))
     C, H, K, oi = [int(v) for v in fx[f"{name}_cfg"]]
