@@ -105,6 +105,44 @@ int ss_segment_reduce(const void* src, const int32_t* indices, const int32_t* id
 int ss_segment_bcast(const void* dout, const int32_t* cluster, const int32_t* idx_ptr, void* dsrc, int64_t n,
                      int channels, int dtype, int mean, ss_stream_t stream);
 
+
+/* ---- libs/pointops, pointops2, pointgroup_ops (fp32 features, int32 indices, offset batches) ------- */
+/* libs/pointops/src/knn_query/knn_query_cuda.cpp:7-16; nsample <= 128; idx -1 / dist2 1e10 padding */
+int ss_knn_query(int m, int nsample, const float* xyz, const float* new_xyz, const int32_t* offset,
+                 const int32_t* new_offset, int num_batches, int32_t* idx, float* dist2, ss_stream_t stream);
+size_t ss_ball_query_workspace_bytes(int m);
+int ss_ball_query(int m, int nsample, float min_radius, float max_radius, const float* xyz, const float* new_xyz,
+                  const int32_t* offset, const int32_t* new_offset, int num_batches, int32_t* idx, float* dist2,
+                  void* workspace, size_t workspace_bytes, ss_stream_t stream);
+int ss_random_ball_query(int m, int nsample, float min_radius, float max_radius, const int32_t* order, const float* xyz,
+                         const float* new_xyz, const int32_t* offset, const int32_t* new_offset, int num_batches,
+                         int32_t* idx, float* dist2, ss_stream_t stream);
+/* tmp (n) f32 initialised to 1e10 by the caller (libs/pointops/functions/sampling.py:19) */
+int ss_farthest_point_sampling(int num_batches, const float* xyz, const int32_t* offset, const int32_t* new_offset,
+                               float* tmp, int32_t* idx, ss_stream_t stream);
+int ss_grouping_fwd(int m, int nsample, int c, const float* input, const int32_t* idx, float* output, ss_stream_t stream);
+int ss_grouping_bwd(int m, int nsample, int c, const float* grad_output, const int32_t* idx, float* grad_input, ss_stream_t stream);
+int ss_subtraction_fwd(int n, int nsample, int c, const float* input1, const float* input2, const int32_t* idx, float* output, ss_stream_t stream);
+int ss_subtraction_bwd(int n, int nsample, int c, const int32_t* idx, const float* grad_output, float* grad_input1, float* grad_input2, ss_stream_t stream);
+int ss_aggregation_fwd(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int32_t* idx, float* output, ss_stream_t stream);
+int ss_aggregation_bwd(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int32_t* idx, const float* grad_output, float* grad_input, float* grad_position, float* grad_weight, ss_stream_t stream);
+int ss_interpolation_fwd(int n, int c, int k, const float* input, const int32_t* idx, const float* weight, float* output, ss_stream_t stream);
+int ss_interpolation_bwd(int n, int c, int k, const float* grad_output, const int32_t* idx, const float* weight, float* grad_input, ss_stream_t stream);
+/* weight == NULL: pointops2 attention_step1 (q . k per edge and head) */
+int ss_attention_relation_fwd(int m, int g, int c, const float* query, const float* key, const float* weight, const int32_t* index_target, const int32_t* index_refer, float* output, ss_stream_t stream);
+int ss_attention_relation_bwd(int m, int g, int c, const float* query, float* grad_query, const float* key, float* grad_key, const float* weight, float* grad_weight, const int32_t* index_target, const int32_t* index_refer, const float* grad_output, ss_stream_t stream);
+/* == pointops2 attention_step2; output / grad_value / grad_* are ACCUMULATED into (caller zeroes) */
+int ss_attention_fusion_fwd(int m, int g, int c, const float* weight, const float* value, const int32_t* index_target, const int32_t* index_refer, float* output, ss_stream_t stream);
+int ss_attention_fusion_bwd(int m, int g, int c, const float* weight, float* grad_weight, const float* value, float* grad_value, const int32_t* index_target, const int32_t* index_refer, const float* grad_output, ss_stream_t stream);
+int ss_rpe_dot_prod_fwd(int n, int m, int h, int hdim, const float* q, const int32_t* index, const float* table, const int32_t* rel_idx, float* output, ss_stream_t stream);
+int ss_rpe_dot_prod_bwd(int n, int m, int h, int hdim, const float* grad_out, const float* q, const int32_t* index, const float* table, const int32_t* rel_idx, float* grad_q, float* grad_table, ss_stream_t stream);
+int ss_rpe_attn_step2_fwd(int n, int m, int h, int hdim, const float* attn, const float* v, const int32_t* index0, const int32_t* index1, const float* table, const int32_t* rel_idx, float* output, ss_stream_t stream);
+int ss_rpe_attn_step2_bwd(int n, int m, int h, int hdim, const float* grad_out, const int32_t* index0, const int32_t* index1, const float* attn, const float* v, const float* table, const int32_t* rel_idx, float* grad_attn, float* grad_v, float* grad_table, ss_stream_t stream);
+/* libs/pointgroup_ops/src/bfs_cluster.cpp:140-145.  total (1) device int = number of pairs found */
+int ss_ballquery_batch_p(int n, int mean_active, float radius, const float* xyz, const int32_t* batch_idxs, const int32_t* batch_offsets, int32_t* idx, int32_t* start_len, int32_t* total, ss_stream_t stream);
+/* HOST pointers (CPU BFS, as the reference) */
+int ss_bfs_cluster(const int32_t* semantic_label, const int32_t* ball_query_idxs, const int32_t* start_len, int n, int threshold, int32_t* cluster_idxs, int64_t cap_points, int32_t* cluster_offsets, int64_t cap_clusters, int32_t* n_clusters, int32_t* n_points);
+
 #ifdef __cplusplus
 }
 #endif

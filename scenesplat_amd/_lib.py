@@ -44,6 +44,29 @@ PROTOTYPES = {
     "ss_gather_add_rows": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p]),
     "ss_segment_reduce": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "ss_segment_bcast": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
+    "ss_knn_query": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
+    "ss_ball_query_workspace_bytes": (c_sz, [c_i]),
+    "ss_ball_query": (c_i, [c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_sz, c_p]),
+    "ss_random_ball_query": (c_i, [c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
+    "ss_farthest_point_sampling": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "ss_grouping_fwd": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "ss_grouping_bwd": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "ss_subtraction_fwd": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "ss_subtraction_bwd": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "ss_aggregation_fwd": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "ss_aggregation_bwd": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "ss_interpolation_fwd": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "ss_interpolation_bwd": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "ss_attention_relation_fwd": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "ss_attention_relation_bwd": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "ss_attention_fusion_fwd": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "ss_attention_fusion_bwd": (c_i, [c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "ss_rpe_dot_prod_fwd": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "ss_rpe_dot_prod_bwd": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "ss_rpe_attn_step2_fwd": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "ss_rpe_attn_step2_bwd": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "ss_ballquery_batch_p": (c_i, [c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "ss_bfs_cluster": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_i64, c_p, c_i64, c_p, c_p]),
 }
 
 _lib = None

@@ -257,6 +257,32 @@ int ss_attn_fwd_simt(const void* qkv, const int32_t* gidx, const int32_t* sidx, 
   return SS_OK;
 }
 
+// bf16 fast path: 16-byte loads, one thread per (slot, head); D % 8 == 0
+__global__ void k_attn_delta_bf16v(const unsigned short* __restrict__ out, const unsigned short* __restrict__ dout,
+                                   const int32_t* __restrict__ sidx, float* __restrict__ delta, int64_t n_pad, int C, int H) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_pad * H) return;
+  int64_t p = gid / H; int h = (int)(gid - p * H);
+  int32_t row = sidx[p];
+  float s = 0.f;
+  if (row >= 0) {
+    const int D = C / H;
+    const uint4* o = reinterpret_cast<const uint4*>(out + (int64_t)row * C + h * D);
+    const uint4* g = reinterpret_cast<const uint4*>(dout + (int64_t)row * C + h * D);
+    for (int i = 0; i < D / 8; ++i) {
+      uint4 a = o[i], b = g[i];
+      const unsigned int* ua = reinterpret_cast<const unsigned int*>(&a);
+      const unsigned int* ub = reinterpret_cast<const unsigned int*>(&b);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s += __uint_as_float(ua[j] << 16) * __uint_as_float(ub[j] << 16);
+        s += __uint_as_float(ua[j] & 0xffff0000u) * __uint_as_float(ub[j] & 0xffff0000u);
+      }
+    }
+  }
+  delta[gid] = s;
+}
+
 template <typename T>
 int ss_attn_delta_t(const void* out, const void* dout, const int32_t* sidx, float* delta, int64_t n_pad, int C, int H,
                     hipStream_t st) {
@@ -266,6 +292,11 @@ int ss_attn_delta_t(const void* out, const void* dout, const int32_t* sidx, floa
 }
 int ss_attn_delta(const void* out, const void* dout, const int32_t* sidx, float* delta, int64_t n_pad, int C, int H,
                   int dtype, hipStream_t st) {
+  if (dtype == SS_BF16 && ((C / H) & 7) == 0) {
+    SS_LAUNCH(k_attn_delta_bf16v, dim3(ss_div_up(n_pad * H, 256)), dim3(256), 0, st, (const unsigned short*)out,
+              (const unsigned short*)dout, sidx, delta, n_pad, C, H);
+    return SS_OK;
+  }
   return dtype == SS_F32 ? ss_attn_delta_t<float>(out, dout, sidx, delta, n_pad, C, H, st)
                          : ss_attn_delta_t<unsigned short>(out, dout, sidx, delta, n_pad, C, H, st);
 }

@@ -1,0 +1,538 @@
+// libs/pointops, libs/pointops2 and libs/pointgroup_ops on gfx950: neighbour queries, sampling and
+// the indexed elementwise families (fp32 features, int32 indices, cumulative `offset` batches, as
+// the reference ABI: libs/pointops/src/pointops_api.cpp:15-31, libs/pointops2/src/pointops_api.cpp:17-44,
+// libs/pointgroup_ops/src/bfs_cluster.cpp:140-145).
+// Differences from the CUDA sources, all deliberate and listed in DESIGN.md:
+//   * launches go to the caller's stream and return a status (the reference uses the legacy default
+//     stream, exit(-1) / throw on error);
+//   * queries stage the candidate points through LDS once per 256 queries instead of one global
+//     read per (query, point); batch lookup is a binary search, not a linear scan;
+//   * relation / step1 forward reduce over channels inside a thread (no atomics); the scatter-style
+//     backward passes keep fp32 atomics (summation order is unspecified in the reference as well);
+//   * ball_query returns true nearest-first candidates and real squared distances in the
+//     subsample branch (the reference heap-sorts a non-heap and stores the index into dist2:
+//     ball_query_cuda_kernel.cu:103,120);
+//   * ballquery_batch_p is two-pass (count, scan, fill): deterministic, no global atomic cursor.
+#include <queue>
+#include <vector>
+#include "common.h"
+#include "../../include/scenesplat_hip.h"
+
+#define PO_THREADS 256
+#define PO_TILE 1024   // candidate points staged per LDS tile
+
+__device__ __forceinline__ int po_batch_of(int i, const int32_t* __restrict__ offset, int nb) {
+  int lo = 0, hi = nb;   // first b with offset[b] > i
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (offset[mid] <= i) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// KNN (knn_query_cuda_kernel.cu:60-104): K nearest of the same batch element, ascending, -1 / 1e10 pad
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void heap_down(float* d, int* ix, int root, int n) {
+  int child = 2 * root + 1;
+  while (child < n) {
+    if (child + 1 < n && d[child + 1] > d[child]) child++;
+    if (d[root] > d[child]) return;
+    float td = d[root]; d[root] = d[child]; d[child] = td;
+    int ti = ix[root]; ix[root] = ix[child]; ix[child] = ti;
+    root = child; child = 2 * root + 1;
+  }
+}
+
+template <int KMAX>
+__global__ void __launch_bounds__(PO_THREADS)
+k_knn(int m, int nsample, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+      const int32_t* __restrict__ offset, const int32_t* __restrict__ new_offset, int nb, int32_t* __restrict__ idx,
+      float* __restrict__ dist2) {
+  __shared__ float tile[PO_TILE * 3];
+  __shared__ int range_s[2];
+  const int q = blockIdx.x * PO_THREADS + threadIdx.x;
+  const bool active = q < m;
+  int start = 0, end = 0;
+  float qx = 0, qy = 0, qz = 0;
+  if (active) {
+    int b = po_batch_of(q, new_offset, nb);
+    start = b == 0 ? 0 : offset[b - 1];
+    end = offset[b];
+    qx = new_xyz[3 * q]; qy = new_xyz[3 * q + 1]; qz = new_xyz[3 * q + 2];
+  }
+  // block-wide candidate range = union of the segments of its first and last query
+  if (threadIdx.x == 0) {
+    int q0 = blockIdx.x * PO_THREADS, q1 = min(m, q0 + PO_THREADS) - 1;
+    int b0 = po_batch_of(q0, new_offset, nb), b1 = po_batch_of(q1, new_offset, nb);
+    range_s[0] = b0 == 0 ? 0 : offset[b0 - 1];
+    range_s[1] = offset[b1];
+  }
+  float bd[KMAX]; int bi[KMAX];
+  for (int i = 0; i < nsample; ++i) { bd[i] = 1e10f; bi[i] = -1; }
+  __syncthreads();
+  const int r0 = range_s[0], r1 = range_s[1];
+  for (int t0 = r0; t0 < r1; t0 += PO_TILE) {
+    const int cnt = min(PO_TILE, r1 - t0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < cnt * 3; e += PO_THREADS) tile[e] = xyz[(int64_t)t0 * 3 + e];
+    __syncthreads();
+    if (active) {
+      int lo = max(start, t0) - t0, hi = min(end, t0 + cnt) - t0;
+      for (int j = lo; j < hi; ++j) {
+        float dx = qx - tile[3 * j], dy = qy - tile[3 * j + 1], dz = qz - tile[3 * j + 2];
+        float d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 < bd[0]) { bd[0] = d2; bi[0] = t0 + j; heap_down<KMAX>(bd, bi, 0, nsample); }
+      }
+    }
+  }
+  if (active) {
+    for (int i = nsample - 1; i > 0; --i) {   // heap sort ascending
+      float td = bd[0]; bd[0] = bd[i]; bd[i] = td;
+      int ti = bi[0]; bi[0] = bi[i]; bi[i] = ti;
+      heap_down<KMAX>(bd, bi, 0, i);
+    }
+    for (int i = 0; i < nsample; ++i) { idx[(int64_t)q * nsample + i] = bi[i]; dist2[(int64_t)q * nsample + i] = bd[i]; }
+  }
+}
+
+extern "C" int ss_knn_query(int m, int nsample, const float* xyz, const float* new_xyz, const int32_t* offset,
+                            const int32_t* new_offset, int num_batches, int32_t* idx, float* dist2, hipStream_t stream) {
+  if (m < 0 || nsample < 1 || nsample > 128 || num_batches < 1) return SS_ERR_ARG;
+  if (m == 0) return SS_OK;
+  dim3 g(ss_div_up(m, PO_THREADS)), b(PO_THREADS);
+  if (nsample <= 1) SS_LAUNCH(k_knn<1>, g, b, 0, stream, m, nsample, xyz, new_xyz, offset, new_offset, num_batches, idx, dist2);
+  else if (nsample <= 8) SS_LAUNCH(k_knn<8>, g, b, 0, stream, m, nsample, xyz, new_xyz, offset, new_offset, num_batches, idx, dist2);
+  else if (nsample <= 32) SS_LAUNCH(k_knn<32>, g, b, 0, stream, m, nsample, xyz, new_xyz, offset, new_offset, num_batches, idx, dist2);
+  else SS_LAUNCH(k_knn<128>, g, b, 0, stream, m, nsample, xyz, new_xyz, offset, new_offset, num_batches, idx, dist2);
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ball query (ball_query_cuda_kernel.cu:58-123): candidates with d2 <= 1e-5 or min2 <= d2 < max2
+// (at most 2048), sorted ascending; all of them (pad -1 / 1e10) or a strided subsample of nsample
+// ---------------------------------------------------------------------------------------------
+#define PO_BALL_CAP 2048
+__global__ void k_ball_query(int m, int nsample, float min2, float max2, const float* __restrict__ xyz,
+                             const float* __restrict__ new_xyz, const int32_t* __restrict__ offset,
+                             const int32_t* __restrict__ new_offset, int nb, int32_t* __restrict__ idx,
+                             float* __restrict__ dist2, float* __restrict__ cand_d, int32_t* __restrict__ cand_i) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m) return;
+  int b = po_batch_of(q, new_offset, nb);
+  int start = b == 0 ? 0 : offset[b - 1], end = offset[b];
+  float qx = new_xyz[3 * q], qy = new_xyz[3 * q + 1], qz = new_xyz[3 * q + 2];
+  float* cd = cand_d + (int64_t)q * PO_BALL_CAP; int32_t* ci = cand_i + (int64_t)q * PO_BALL_CAP;
+  int num = 0;
+  for (int i = start; i < end && num < PO_BALL_CAP; ++i) {
+    float dx = qx - xyz[3 * i], dy = qy - xyz[3 * i + 1], dz = qz - xyz[3 * i + 2];
+    float d2 = dx * dx + dy * dy + dz * dz;
+    if (d2 <= 1e-5f || (d2 >= min2 && d2 < max2)) { cd[num] = d2; ci[num] = i; ++num; }
+  }
+  // heapify + heap sort ascending (ties keep no particular order, as in any heap sort)
+  for (int r = num / 2 - 1; r >= 0; --r) heap_down<0>(cd, ci, r, num);
+  for (int i = num - 1; i > 0; --i) {
+    float td = cd[0]; cd[0] = cd[i]; cd[i] = td;
+    int ti = ci[0]; ci[0] = ci[i]; ci[i] = ti;
+    heap_down<0>(cd, ci, 0, i);
+  }
+  int32_t* oi = idx + (int64_t)q * nsample; float* od = dist2 + (int64_t)q * nsample;
+  if (num <= nsample) {
+    for (int i = 0; i < num; ++i) { oi[i] = ci[i]; od[i] = cd[i]; }
+    for (int i = num; i < nsample; ++i) { oi[i] = -1; od[i] = 1e10f; }
+  } else {
+    float sep = (float)num / nsample;
+    for (int i = 0; i < nsample; ++i) { int k = (int)(sep * i); oi[i] = ci[k]; od[i] = cd[k]; }
+  }
+}
+extern "C" size_t ss_ball_query_workspace_bytes(int m) { return (size_t)(m > 0 ? m : 1) * PO_BALL_CAP * 8; }
+extern "C" int ss_ball_query(int m, int nsample, float min_radius, float max_radius, const float* xyz,
+                             const float* new_xyz, const int32_t* offset, const int32_t* new_offset, int num_batches,
+                             int32_t* idx, float* dist2, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (m < 0 || nsample < 1 || num_batches < 1 || !(min_radius < max_radius)) return SS_ERR_ARG;
+  if (workspace_bytes < ss_ball_query_workspace_bytes(m)) return SS_ERR_WORKSPACE;
+  if (m == 0) return SS_OK;
+  float* cd = (float*)workspace; int32_t* ci = (int32_t*)((char*)workspace + (size_t)m * PO_BALL_CAP * 4);
+  SS_LAUNCH(k_ball_query, dim3(ss_div_up(m, 128)), dim3(128), 0, stream, m, nsample, min_radius * min_radius,
+            max_radius * max_radius, xyz, new_xyz, offset, new_offset, num_batches, idx, dist2, cd, ci);
+  return SS_OK;
+}
+
+// random ball query (random_ball_query_cuda_kernel.cu:58-108): first nsample hits along `order`
+__global__ void k_random_ball_query(int m, int nsample, float min2, float max2, const int32_t* __restrict__ order,
+                                    const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                    const int32_t* __restrict__ offset, const int32_t* __restrict__ new_offset, int nb,
+                                    int32_t* __restrict__ idx, float* __restrict__ dist2) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m) return;
+  int b = po_batch_of(q, new_offset, nb);
+  int start = b == 0 ? 0 : offset[b - 1], end = offset[b];
+  float qx = new_xyz[3 * q], qy = new_xyz[3 * q + 1], qz = new_xyz[3 * q + 2];
+  int32_t* oi = idx + (int64_t)q * nsample; float* od = dist2 + (int64_t)q * nsample;
+  int cnt = 0;
+  for (int i = start; i < end && cnt < nsample; ++i) {
+    int o = order[i];
+    float dx = qx - xyz[3 * o], dy = qy - xyz[3 * o + 1], dz = qz - xyz[3 * o + 2];
+    float d2 = dx * dx + dy * dy + dz * dz;
+    if (d2 <= 1e-5f || (d2 >= min2 && d2 < max2)) { od[cnt] = d2; oi[cnt] = o; ++cnt; }
+  }
+  for (int i = cnt; i < nsample; ++i) { oi[i] = -1; od[i] = 1e10f; }
+}
+extern "C" int ss_random_ball_query(int m, int nsample, float min_radius, float max_radius, const int32_t* order,
+                                    const float* xyz, const float* new_xyz, const int32_t* offset,
+                                    const int32_t* new_offset, int num_batches, int32_t* idx, float* dist2,
+                                    hipStream_t stream) {
+  if (m < 0 || nsample < 1 || num_batches < 1 || !(min_radius < max_radius)) return SS_ERR_ARG;
+  if (m == 0) return SS_OK;
+  SS_LAUNCH(k_random_ball_query, dim3(ss_div_up(m, 128)), dim3(128), 0, stream, m, nsample, min_radius * min_radius,
+            max_radius * max_radius, order, xyz, new_xyz, offset, new_offset, num_batches, idx, dist2);
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// farthest point sampling (sampling_cuda_kernel.cu:14-129): one workgroup per batch element,
+// tmp[k] = min(tmp[k], d(k, last)); block arg-max; first sample = first point of the element
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_fps(const float* __restrict__ xyz, const int32_t* __restrict__ offset, const int32_t* __restrict__ new_offset,
+      float* __restrict__ tmp, int32_t* __restrict__ idx) {
+  __shared__ float sd[16]; __shared__ int si[16]; __shared__ int cur_s;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int start = b == 0 ? 0 : offset[b - 1], end = offset[b];
+  const int ostart = b == 0 ? 0 : new_offset[b - 1], oend = new_offset[b];
+  if (oend <= ostart || end <= start) return;
+  int old = start;
+  if (tid == 0) idx[ostart] = start;
+  for (int j = ostart + 1; j < oend; ++j) {
+    float x1 = xyz[3 * old], y1 = xyz[3 * old + 1], z1 = xyz[3 * old + 2];
+    float best = -1.f; int besti = start;
+    for (int k = start + tid; k < end; k += 1024) {
+      float dx = xyz[3 * k] - x1, dy = xyz[3 * k + 1] - y1, dz = xyz[3 * k + 2] - z1;
+      float d = fminf(dx * dx + dy * dy + dz * dz, tmp[k]);
+      tmp[k] = d;
+      if (d > best) { best = d; besti = k; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {   // wave arg-max (lowest index wins ties)
+      float ob = __shfl_xor(best, o, 64); int oi = __shfl_xor(besti, o, 64);
+      if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if ((tid & 63) == 0) { sd[tid >> 6] = best; si[tid >> 6] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+      float bb = sd[0]; int bi = si[0];
+      for (int w = 1; w < 16; ++w) if (sd[w] > bb || (sd[w] == bb && si[w] < bi)) { bb = sd[w]; bi = si[w]; }
+      cur_s = bi; idx[j] = bi;
+    }
+    __syncthreads();
+    old = cur_s;
+  }
+}
+extern "C" int ss_farthest_point_sampling(int num_batches, const float* xyz, const int32_t* offset,
+                                          const int32_t* new_offset, float* tmp, int32_t* idx, hipStream_t stream) {
+  if (num_batches < 1) return SS_ERR_ARG;
+  SS_LAUNCH(k_fps, dim3(num_batches), dim3(1024), 0, stream, xyz, offset, new_offset, tmp, idx);
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// indexed elementwise families (fp32)
+// ---------------------------------------------------------------------------------------------
+#define PO_EW(name, total, ...)                                                                     \
+  if ((total) <= 0) return SS_OK;                                                                   \
+  SS_LAUNCH(name, dim3(ss_div_up((total), 256)), dim3(256), 0, stream, __VA_ARGS__);                \
+  return SS_OK;
+
+__global__ void k_grouping_fwd(int64_t total, int nsample, int c, const float* __restrict__ in, const int32_t* __restrict__ idx, float* __restrict__ out) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (g >= total) return;
+  int ci = g % c; int64_t ms = g / c;
+  int j = idx[ms];
+  out[g] = j >= 0 ? in[(int64_t)j * c + ci] : 0.f;
+}
+__global__ void k_grouping_bwd(int64_t total, int nsample, int c, const float* __restrict__ gout, const int32_t* __restrict__ idx, float* __restrict__ gin) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (g >= total) return;
+  int ci = g % c; int64_t ms = g / c;
+  int j = idx[ms];
+  if (j >= 0) atomicAdd(gin + (int64_t)j * c + ci, gout[g]);
+}
+extern "C" int ss_grouping_fwd(int m, int nsample, int c, const float* input, const int32_t* idx, float* output, hipStream_t stream) {
+  PO_EW(k_grouping_fwd, (int64_t)m * nsample * c, (int64_t)m * nsample * c, nsample, c, input, idx, output)
+}
+extern "C" int ss_grouping_bwd(int m, int nsample, int c, const float* grad_output, const int32_t* idx, float* grad_input, hipStream_t stream) {
+  PO_EW(k_grouping_bwd, (int64_t)m * nsample * c, (int64_t)m * nsample * c, nsample, c, grad_output, idx, grad_input)
+}
+
+// subtraction: out[n,s,c] = in1[n,c] - in2[idx[n,s],c]  (subtraction_cuda_kernel.cu:5-30)
+__global__ void k_sub_fwd(int64_t total, int nsample, int c, const float* __restrict__ a, const float* __restrict__ b, const int32_t* __restrict__ idx, float* __restrict__ out) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (g >= total) return;
+  int ci = g % c; int64_t ns = g / c; int64_t ni = ns / nsample;
+  out[g] = a[ni * c + ci] - b[(int64_t)idx[ns] * c + ci];
+}
+__global__ void k_sub_bwd(int64_t total, int nsample, int c, const int32_t* __restrict__ idx, const float* __restrict__ gout, float* __restrict__ ga, float* __restrict__ gb) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (g >= total) return;   // one thread per (n, c): in1 grad without atomics
+  int ci = g % c; int64_t ni = g / c;
+  float s = 0.f;
+  for (int k = 0; k < nsample; ++k) {
+    float v = gout[(ni * nsample + k) * c + ci];
+    s += v;
+    atomicAdd(gb + (int64_t)idx[ni * nsample + k] * c + ci, -v);
+  }
+  ga[g] = s;
+}
+extern "C" int ss_subtraction_fwd(int n, int nsample, int c, const float* input1, const float* input2, const int32_t* idx, float* output, hipStream_t stream) {
+  PO_EW(k_sub_fwd, (int64_t)n * nsample * c, (int64_t)n * nsample * c, nsample, c, input1, input2, idx, output)
+}
+extern "C" int ss_subtraction_bwd(int n, int nsample, int c, const int32_t* idx, const float* grad_output, float* grad_input1, float* grad_input2, hipStream_t stream) {
+  PO_EW(k_sub_bwd, (int64_t)n * c, (int64_t)n * c, nsample, c, idx, grad_output, grad_input1, grad_input2)
+}
+
+// aggregation: out[n,c] = sum_s (in[idx[n,s],c] + pos[n,s,c]) * w[n,s,c % w_c]  (aggregation_cuda_kernel.cu:5-39)
+__global__ void k_agg_fwd(int64_t total, int nsample, int c, int wc, const float* __restrict__ in, const float* __restrict__ pos, const float* __restrict__ w, const int32_t* __restrict__ idx, float* __restrict__ out) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (g >= total) return;
+  int ci = g % c; int64_t ni = g / c; int wi = ci % wc;
+  float s = 0.f;
+  for (int k = 0; k < nsample; ++k) {
+    int64_t ns = ni * nsample + k;
+    s += (in[(int64_t)idx[ns] * c + ci] + pos[ns * c + ci]) * w[ns * wc + wi];
+  }
+  out[g] = s;
+}
+__global__ void k_agg_bwd(int64_t total, int nsample, int c, int wc, const float* __restrict__ in, const float* __restrict__ pos, const float* __restrict__ w, const int32_t* __restrict__ idx, const float* __restrict__ gout, float* __restrict__ gin, float* __restrict__ gpos, float* __restrict__ gw) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (g >= total) return;
+  int ci = g % c; int64_t ni = g / c; int wi = ci % wc;
+  float go = gout[g];
+  for (int k = 0; k < nsample; ++k) {
+    int64_t ns = ni * nsample + k;
+    int64_t ii = (int64_t)idx[ns] * c + ci;
+    float wv = w[ns * wc + wi];
+    atomicAdd(gin + ii, go * wv);
+    gpos[ns * c + ci] = go * wv;
+    atomicAdd(gw + ns * wc + wi, go * (in[ii] + pos[ns * c + ci]));
+  }
+}
+extern "C" int ss_aggregation_fwd(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int32_t* idx, float* output, hipStream_t stream) {
+  if (w_c < 1) return SS_ERR_ARG;
+  PO_EW(k_agg_fwd, (int64_t)n * c, (int64_t)n * c, nsample, c, w_c, input, position, weight, idx, output)
+}
+extern "C" int ss_aggregation_bwd(int n, int nsample, int c, int w_c, const float* input, const float* position, const float* weight, const int32_t* idx, const float* grad_output, float* grad_input, float* grad_position, float* grad_weight, hipStream_t stream) {
+  if (w_c < 1) return SS_ERR_ARG;
+  PO_EW(k_agg_bwd, (int64_t)n * c, (int64_t)n * c, nsample, c, w_c, input, position, weight, idx, grad_output, grad_input, grad_position, grad_weight)
+}
+
+// interpolation: out[n,c] = sum_k in[idx[n,k],c] * w[n,k]  (interpolation_cuda_kernel.cu:5-33)
+__global__ void k_interp_fwd(int64_t total, int c, int k, const float* __restrict__ in, const int32_t* __restrict__ idx, const float* __restrict__ w, float* __restrict__ out) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (g >= total) return;
+  int ci = g % c; int64_t ni = g / c;
+  float s = 0.f;
+  for (int i = 0; i < k; ++i) s += in[(int64_t)idx[ni * k + i] * c + ci] * w[ni * k + i];
+  out[g] = s;
+}
+__global__ void k_interp_bwd(int64_t total, int c, int k, const float* __restrict__ gout, const int32_t* __restrict__ idx, const float* __restrict__ w, float* __restrict__ gin) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (g >= total) return;
+  int ci = g % c; int64_t ni = g / c;
+  for (int i = 0; i < k; ++i) atomicAdd(gin + (int64_t)idx[ni * k + i] * c + ci, gout[g] * w[ni * k + i]);
+}
+extern "C" int ss_interpolation_fwd(int n, int c, int k, const float* input, const int32_t* idx, const float* weight, float* output, hipStream_t stream) {
+  PO_EW(k_interp_fwd, (int64_t)n * c, (int64_t)n * c, c, k, input, idx, weight, output)
+}
+extern "C" int ss_interpolation_bwd(int n, int c, int k, const float* grad_output, const int32_t* idx, const float* weight, float* grad_input, hipStream_t stream) {
+  PO_EW(k_interp_bwd, (int64_t)n * c, (int64_t)n * c, c, k, grad_output, idx, weight, grad_input)
+}
+
+// attention relation step: out[r,g] = sum_c q[tgt[r],g,c] k[ref[r],g,c] w[c]  (pointops attention_cuda_kernel.cu:9-46)
+// with w == NULL this is pointops2 attention_step1 (attention_cuda_kernel.cu:7-38): out[m,h] = q[i0[m],h,:] . k[i1[m],h,:]
+__global__ void k_relation_fwd(int64_t total, int g_, int c, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ w, const int32_t* __restrict__ it, const int32_t* __restrict__ ir, float* __restrict__ out) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (gid >= total) return;
+  int gi = gid % g_; int64_t r = gid / g_;
+  const float* qp = q + ((int64_t)it[r] * g_ + gi) * c; const float* kp = k + ((int64_t)ir[r] * g_ + gi) * c;
+  float s = 0.f;
+  for (int ci = 0; ci < c; ++ci) s += qp[ci] * kp[ci] * (w ? w[ci] : 1.f);
+  out[gid] = s;
+}
+__global__ void k_relation_bwd(int64_t total, int g_, int c, const float* __restrict__ q, float* __restrict__ gq, const float* __restrict__ k, float* __restrict__ gk, const float* __restrict__ w, float* __restrict__ gw, const int32_t* __restrict__ it, const int32_t* __restrict__ ir, const float* __restrict__ gout) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (gid >= total) return;   // one thread per (r, g, c)
+  int ci = gid % c; int64_t rg = gid / c; int gi = rg % g_; int64_t r = rg / g_;
+  int64_t qi = ((int64_t)it[r] * g_ + gi) * c + ci, ki = ((int64_t)ir[r] * g_ + gi) * c + ci;
+  float go = gout[rg], wv = w ? w[ci] : 1.f;
+  atomicAdd(gq + qi, go * k[ki] * wv);
+  atomicAdd(gk + ki, go * q[qi] * wv);
+  if (w) atomicAdd(gw + ci, go * k[ki] * q[qi]);
+}
+extern "C" int ss_attention_relation_fwd(int m, int g, int c, const float* query, const float* key, const float* weight, const int32_t* index_target, const int32_t* index_refer, float* output, hipStream_t stream) {
+  PO_EW(k_relation_fwd, (int64_t)m * g, (int64_t)m * g, g, c, query, key, weight, index_target, index_refer, output)
+}
+extern "C" int ss_attention_relation_bwd(int m, int g, int c, const float* query, float* grad_query, const float* key, float* grad_key, const float* weight, float* grad_weight, const int32_t* index_target, const int32_t* index_refer, const float* grad_output, hipStream_t stream) {
+  PO_EW(k_relation_bwd, (int64_t)m * g * c, (int64_t)m * g * c, g, c, query, grad_query, key, grad_key, weight, grad_weight, index_target, index_refer, grad_output)
+}
+
+// attention fusion step: out[tgt[r],g,c] += w[r,g] v[ref[r],g,c]  (pointops :49-86) == pointops2 attention_step2 (:58-87)
+__global__ void k_fusion_fwd(int64_t total, int g_, int c, const float* __restrict__ w, const float* __restrict__ v, const int32_t* __restrict__ it, const int32_t* __restrict__ ir, float* __restrict__ out) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (gid >= total) return;
+  int ci = gid % c; int64_t rg = gid / c; int gi = rg % g_; int64_t r = rg / g_;
+  atomicAdd(out + ((int64_t)it[r] * g_ + gi) * c + ci, w[rg] * v[((int64_t)ir[r] * g_ + gi) * c + ci]);
+}
+__global__ void k_fusion_bwd(int64_t total, int g_, int c, const float* __restrict__ w, float* __restrict__ gw, const float* __restrict__ v, float* __restrict__ gv, const int32_t* __restrict__ it, const int32_t* __restrict__ ir, const float* __restrict__ gout) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (gid >= total) return;   // one thread per (r, g): grad_weight without atomics
+  int gi = gid % g_; int64_t r = gid / g_;
+  const float* gp = gout + ((int64_t)it[r] * g_ + gi) * c; int64_t vb = ((int64_t)ir[r] * g_ + gi) * c;
+  float s = 0.f, wv = w[gid];
+  for (int ci = 0; ci < c; ++ci) { float go = gp[ci]; s += go * v[vb + ci]; atomicAdd(gv + vb + ci, go * wv); }
+  gw[gid] = s;
+}
+extern "C" int ss_attention_fusion_fwd(int m, int g, int c, const float* weight, const float* value, const int32_t* index_target, const int32_t* index_refer, float* output, hipStream_t stream) {
+  PO_EW(k_fusion_fwd, (int64_t)m * g * c, (int64_t)m * g * c, g, c, weight, value, index_target, index_refer, output)
+}
+extern "C" int ss_attention_fusion_bwd(int m, int g, int c, const float* weight, float* grad_weight, const float* value, float* grad_value, const int32_t* index_target, const int32_t* index_refer, const float* grad_output, hipStream_t stream) {
+  PO_EW(k_fusion_bwd, (int64_t)m * g, (int64_t)m * g, g, c, weight, grad_weight, value, grad_value, index_target, index_refer, grad_output)
+}
+
+// pointops2 relative position encoding (rpe/relative_pos_encoding_cuda_kernel.cu:7-118)
+// table (L, h, hdim, 3); rel_idx (M, 3)
+__global__ void k_rpe_dot_fwd(int64_t total, int h, int hd, const float* __restrict__ q, const int32_t* __restrict__ index, const float* __restrict__ table, const int32_t* __restrict__ rel, float* __restrict__ out) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (gid >= total) return;   // (m, h)
+  int hi = gid % h; int64_t mi = gid / h;
+  const float* qp = q + ((int64_t)index[mi] * h + hi) * hd;
+  float s = 0.f;
+  for (int d = 0; d < 3; ++d) {
+    const float* tp = table + ((int64_t)rel[mi * 3 + d] * h + hi) * hd * 3 + d;
+    for (int ci = 0; ci < hd; ++ci) s += qp[ci] * tp[ci * 3];
+  }
+  out[gid] = s;
+}
+__global__ void k_rpe_dot_bwd(int64_t total, int h, int hd, const float* __restrict__ gout, const float* __restrict__ q, const int32_t* __restrict__ index, const float* __restrict__ table, const int32_t* __restrict__ rel, float* __restrict__ gq, float* __restrict__ gt) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (gid >= total) return;   // (m, h, c)
+  int ci = gid % hd; int64_t mh = gid / hd; int hi = mh % h; int64_t mi = mh / h;
+  int64_t qi = ((int64_t)index[mi] * h + hi) * hd + ci;
+  float go = gout[mh], qv = q[qi], s = 0.f;
+  for (int d = 0; d < 3; ++d) {
+    int64_t ti = (((int64_t)rel[mi * 3 + d] * h + hi) * hd + ci) * 3 + d;
+    s += go * table[ti];
+    atomicAdd(gt + ti, go * qv);
+  }
+  atomicAdd(gq + qi, s);
+}
+extern "C" int ss_rpe_dot_prod_fwd(int n, int m, int h, int hdim, const float* q, const int32_t* index, const float* table, const int32_t* rel_idx, float* output, hipStream_t stream) {
+  PO_EW(k_rpe_dot_fwd, (int64_t)m * h, (int64_t)m * h, h, hdim, q, index, table, rel_idx, output)
+}
+extern "C" int ss_rpe_dot_prod_bwd(int n, int m, int h, int hdim, const float* grad_out, const float* q, const int32_t* index, const float* table, const int32_t* rel_idx, float* grad_q, float* grad_table, hipStream_t stream) {
+  PO_EW(k_rpe_dot_bwd, (int64_t)m * h * hdim, (int64_t)m * h * hdim, h, hdim, grad_out, q, index, table, rel_idx, grad_q, grad_table)
+}
+// out[i0[m],h,c] += attn[m,h] * (v[i1[m],h,c] + sum_d table[rel[m,d],h,c,d])   (the reference adds v/3 per dim)
+__global__ void k_rpe_step2_fwd(int64_t total, int h, int hd, const float* __restrict__ attn, const float* __restrict__ v, const int32_t* __restrict__ i0, const int32_t* __restrict__ i1, const float* __restrict__ table, const int32_t* __restrict__ rel, float* __restrict__ out) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (gid >= total) return;   // (m, h, c)
+  int ci = gid % hd; int64_t mh = gid / hd; int hi = mh % h; int64_t mi = mh / h;
+  float t = 0.f;
+  for (int d = 0; d < 3; ++d) t += table[(((int64_t)rel[mi * 3 + d] * h + hi) * hd + ci) * 3 + d];
+  float val = attn[mh] * (v[((int64_t)i1[mi] * h + hi) * hd + ci] + t);
+  atomicAdd(out + ((int64_t)i0[mi] * h + hi) * hd + ci, val);
+}
+__global__ void k_rpe_step2_bwd(int64_t total, int h, int hd, const float* __restrict__ gout, const int32_t* __restrict__ i0, const int32_t* __restrict__ i1, const float* __restrict__ attn, const float* __restrict__ v, const float* __restrict__ table, const int32_t* __restrict__ rel, float* __restrict__ gattn, float* __restrict__ gv, float* __restrict__ gt) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (gid >= total) return;   // (m, h, c)
+  int ci = gid % hd; int64_t mh = gid / hd; int hi = mh % h; int64_t mi = mh / h;
+  int64_t vi = ((int64_t)i1[mi] * h + hi) * hd + ci;
+  float go = gout[((int64_t)i0[mi] * h + hi) * hd + ci], a = attn[mh], t = 0.f;
+  for (int d = 0; d < 3; ++d) {
+    int64_t ti = (((int64_t)rel[mi * 3 + d] * h + hi) * hd + ci) * 3 + d;
+    t += table[ti];
+    atomicAdd(gt + ti, go * a);
+  }
+  atomicAdd(gattn + mh, go * (v[vi] + t));
+  atomicAdd(gv + vi, go * a);
+}
+extern "C" int ss_rpe_attn_step2_fwd(int n, int m, int h, int hdim, const float* attn, const float* v, const int32_t* index0, const int32_t* index1, const float* table, const int32_t* rel_idx, float* output, hipStream_t stream) {
+  PO_EW(k_rpe_step2_fwd, (int64_t)m * h * hdim, (int64_t)m * h * hdim, h, hdim, attn, v, index0, index1, table, rel_idx, output)
+}
+extern "C" int ss_rpe_attn_step2_bwd(int n, int m, int h, int hdim, const float* grad_out, const int32_t* index0, const int32_t* index1, const float* attn, const float* v, const float* table, const int32_t* rel_idx, float* grad_attn, float* grad_v, float* grad_table, hipStream_t stream) {
+  PO_EW(k_rpe_step2_bwd, (int64_t)m * h * hdim, (int64_t)m * h * hdim, h, hdim, grad_out, index0, index1, attn, v, table, rel_idx, grad_attn, grad_v, grad_table)
+}
+
+// ---------------------------------------------------------------------------------------------
+// pointgroup_ops: ballquery_batch_p (bfs_cluster_kernel.cu:16-91), two-pass deterministic form
+// ---------------------------------------------------------------------------------------------
+#define PG_CAP 1000
+__global__ void k_bq_count(int n, float r2, const float* __restrict__ xyz, const int32_t* __restrict__ bidx, const int32_t* __restrict__ boff, int32_t* __restrict__ start_len) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+  float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+  int b = bidx[i], cnt = 0;
+  for (int k = boff[b]; k < boff[b + 1] && cnt < PG_CAP; ++k) {
+    float dx = x - xyz[3 * k], dy = y - xyz[3 * k + 1], dz = z - xyz[3 * k + 2];
+    if (dx * dx + dy * dy + dz * dz < r2) ++cnt;
+  }
+  start_len[2 * i + 1] = cnt;
+}
+__global__ void k_bq_scan(int n, int32_t* __restrict__ start_len, int32_t* __restrict__ total) {   // single block, sequential chunks
+  __shared__ int carry;
+  __shared__ int buf[1024];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    int i = base + threadIdx.x;
+    int v = i < n ? start_len[2 * i + 1] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      int add = threadIdx.x >= o ? buf[threadIdx.x - o] : 0;
+      __syncthreads();
+      buf[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < n) start_len[2 * i] = carry + buf[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += buf[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+__global__ void k_bq_fill(int n, float r2, int64_t cap, const float* __restrict__ xyz, const int32_t* __restrict__ bidx, const int32_t* __restrict__ boff, const int32_t* __restrict__ start_len, int32_t* __restrict__ idx) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+  float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+  int b = bidx[i], cnt = 0;
+  int64_t pos = start_len[2 * i];
+  for (int k = boff[b]; k < boff[b + 1] && cnt < PG_CAP; ++k) {
+    float dx = x - xyz[3 * k], dy = y - xyz[3 * k + 1], dz = z - xyz[3 * k + 2];
+    if (dx * dx + dy * dy + dz * dz < r2) { if (pos + cnt < cap) idx[pos + cnt] = k; ++cnt; }
+  }
+}
+extern "C" int ss_ballquery_batch_p(int n, int mean_active, float radius, const float* xyz, const int32_t* batch_idxs, const int32_t* batch_offsets, int32_t* idx, int32_t* start_len, int32_t* total, hipStream_t stream) {
+  if (n < 0 || mean_active < 1) return SS_ERR_ARG;
+  if (n == 0) { hipMemsetAsync(total, 0, 4, stream); return SS_OK; }
+  float r2 = radius * radius;
+  SS_LAUNCH(k_bq_count, dim3(ss_div_up(n, 128)), dim3(128), 0, stream, n, r2, xyz, batch_idxs, batch_offsets, start_len);
+  SS_LAUNCH(k_bq_scan, dim3(1), dim3(1024), 0, stream, n, start_len, total);
+  SS_LAUNCH(k_bq_fill, dim3(ss_div_up(n, 128)), dim3(128), 0, stream, n, r2, (int64_t)n * mean_active, xyz, batch_idxs, batch_offsets, start_len, idx);
+  return SS_OK;
+}
+
+// bfs_cluster (bfs_cluster.cpp:53-137): HOST function, host pointers; connected components of the
+// ball-query graph restricted to equal semantic label, clusters with >= threshold points.
+// cluster_idxs (cap_points, 2), cluster_offsets (cap_clusters + 1); sizes returned in n_clusters / n_points;
+// SS_ERR_WORKSPACE (with the sizes filled in) when a capacity is too small.
+extern "C" int ss_bfs_cluster(const int32_t* semantic_label, const int32_t* ball_query_idxs, const int32_t* start_len, int n, int threshold, int32_t* cluster_idxs, int64_t cap_points, int32_t* cluster_offsets, int64_t cap_clusters, int32_t* n_clusters, int32_t* n_points) {
+  if (n < 0) return SS_ERR_ARG;
+  std::vector<char> visited((size_t)n, 0);
+  std::vector<std::vector<int32_t>> ccs;
+  int64_t sum = 0;
+  for (int i = 0; i < n; ++i) {
+    if (visited[i]) continue;
+    std::vector<int32_t> cc; std::queue<int32_t> Q;
+    cc.push_back(i); visited[i] = 1; Q.push(i);
+    while (!Q.empty()) {
+      int cur = Q.front(); Q.pop();
+      int s = start_len[2 * cur], len = start_len[2 * cur + 1], lab = semantic_label[cur];
+      for (int k = s; k < s + len; ++k) {
+        int j = ball_query_idxs[k];
+        if (semantic_label[j] != lab || visited[j]) continue;
+        cc.push_back(j); visited[j] = 1; Q.push(j);
+      }
+    }
+    if ((int)cc.size() >= threshold) { sum += (int64_t)cc.size(); ccs.push_back(std::move(cc)); }
+  }
+  *n_clusters = (int32_t)ccs.size(); *n_points = (int32_t)sum;
+  if (sum > cap_points || (int64_t)ccs.size() > cap_clusters) return SS_ERR_WORKSPACE;
+  cluster_offsets[0] = 0;
+  for (size_t c = 0; c < ccs.size(); ++c) {
+    cluster_offsets[c + 1] = cluster_offsets[c] + (int32_t)ccs[c].size();
+    for (size_t j = 0; j < ccs[c].size(); ++j) {
+      cluster_idxs[2 * (cluster_offsets[c] + j)] = (int32_t)c;
+      cluster_idxs[2 * (cluster_offsets[c] + j) + 1] = ccs[c][j];
+    }
+  }
+  return SS_OK;
+}

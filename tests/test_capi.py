@@ -74,3 +74,18 @@ def test_registry_build_contract():
         MODELS.build(dict(type="nope"))
     with pytest.raises(TypeError, match="PointTransformerV3"):
         MODELS.build(dict(type="PT-v3m1", bogus=1))
+
+
+def test_bfs_cluster_host_function_matches_oracle():
+    """pointgroup bfs_cluster is a HOST function of the C-ABI (as in the reference): testable without a GPU."""
+    import numpy as np
+    import torch
+    from oracle import pointops as opo
+    from scenesplat_amd import pointops as po
+    g = np.random.default_rng(0)
+    xyz = g.random((300, 3), dtype=np.float32)
+    ridx, rsl = opo.ballquery_batch_p(xyz, np.zeros(300, int), np.array([0, 300]), 0.15)
+    lab = (xyz[:, 0] > 0.5).astype(np.int32)
+    ci, co = po.bfs_cluster(torch.as_tensor(lab), torch.as_tensor(ridx), torch.as_tensor(rsl), 5)
+    ri, ro = opo.bfs_cluster(lab, ridx, rsl, 5)
+    assert np.array_equal(ci.numpy(), ri) and np.array_equal(co.numpy(), ro) and len(ro) > 2

@@ -1,0 +1,173 @@
+"""GPU parity: libs/pointops, pointops2, pointgroup_ops replacements vs the numpy oracle
+("parity unpinned": the reference has no fixtures for these; see oracle/pointops.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pointops as opo
+
+pytestmark = pytest.mark.gpu
+
+
+def data(seed=0, counts=(300, 500, 41)):
+    g = np.random.default_rng(seed)
+    n = sum(counts)
+    xyz = g.random((n, 3), dtype=np.float32)
+    offset = np.cumsum(counts)
+    return xyz, offset
+
+
+def cu(a, dt=None):
+    t = torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    return t.to(dt) if dt is not None else t
+
+
+@pytest.mark.parametrize("k", [1, 3, 16, 40])
+def test_knn_query(k):
+    from scenesplat_amd import pointops as po
+    xyz, off = data()
+    new_xyz, noff = data(1, (120, 80, 30))
+    idx, dist = po.knn_query(k, cu(xyz), cu(off), cu(new_xyz), cu(noff))
+    ridx, rd2 = opo.knn_query(k, xyz, off, new_xyz, noff)
+    assert np.allclose(dist.cpu().numpy() ** 2, rd2, rtol=1e-4, atol=1e-7)
+    assert np.array_equal(idx.cpu().numpy(), ridx)        # continuous random coords: no distance ties
+    # self query, padding when the segment is smaller than k
+    idx2, d2 = po.knn_query(50, cu(xyz), cu(off))
+    r2, rd = opo.knn_query(50, xyz, off)
+    assert np.array_equal(idx2.cpu().numpy(), r2)
+    assert (idx2[-41:, 41:] == -1).all()
+
+
+def test_ball_and_random_ball_query():
+    from scenesplat_amd import pointops as po
+    xyz, off = data(2)
+    idx, dist = po.ball_query(16, 0.25, 0.05, cu(xyz), cu(off))
+    ridx, rd2 = opo.ball_query(16, 0.25, 0.05, xyz, off)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.allclose(dist.cpu().numpy() ** 2, rd2, rtol=1e-4)
+    order = np.concatenate([np.random.default_rng(3).permutation(np.arange(s, e)) for s, e in zip([0] + off[:-1].tolist(), off)])
+    idx, dist = po.random_ball_query(8, 0.3, 0.0, cu(xyz), cu(off), order=cu(order, torch.int32))
+    ridx, rd2 = opo.random_ball_query(8, 0.3, 0.0, order, xyz, off)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.allclose(dist.cpu().numpy() ** 2, rd2, rtol=1e-4)
+
+
+def test_farthest_point_sampling():
+    from scenesplat_amd import pointops as po
+    xyz, off = data(4, (1500, 700, 9))
+    noff = np.cumsum([100, 33, 9])
+    idx = po.farthest_point_sampling(cu(xyz), cu(off), cu(noff))
+    assert np.array_equal(idx.cpu().numpy(), opo.farthest_point_sampling(xyz, off, noff))
+
+
+def test_grouping_subtraction_aggregation_interpolation():
+    from scenesplat_amd import pointops as po
+    g = np.random.default_rng(5)
+    n, m, ns, c, wc = 200, 150, 8, 12, 4
+    feat = g.standard_normal((n, c)).astype(np.float32)
+    idx = g.integers(-1, n, (m, ns))
+    f = cu(feat).requires_grad_(True)
+    out = po.grouping2(f, cu(idx, torch.int32))
+    assert np.allclose(out.detach().cpu().numpy(), opo.grouping(feat, idx), atol=1e-6)
+    cot = g.standard_normal((m, ns, c)).astype(np.float32)
+    (out * cu(cot)).sum().backward()
+    ref = np.zeros_like(feat); np.add.at(ref, idx[idx >= 0], cot[idx >= 0])
+    assert np.allclose(f.grad.cpu().numpy(), ref, atol=1e-4)
+    # subtraction
+    idx = g.integers(0, n, (n, ns))
+    a, b = cu(feat).requires_grad_(True), cu(feat[::-1].copy()).requires_grad_(True)
+    out = po.subtraction(a, b, cu(idx, torch.int32))
+    assert np.allclose(out.detach().cpu().numpy(), opo.subtraction(feat, feat[::-1], idx), atol=1e-6)
+    cot = g.standard_normal((n, ns, c)).astype(np.float32)
+    (out * cu(cot)).sum().backward()
+    assert np.allclose(a.grad.cpu().numpy(), cot.sum(1), atol=1e-4)
+    ref = np.zeros_like(feat); np.add.at(ref, idx, -cot)
+    assert np.allclose(b.grad.cpu().numpy(), ref, atol=1e-4)
+    # aggregation (torch autograd of the same formula as reference for the backward)
+    pos = g.standard_normal((n, ns, c)).astype(np.float32); w = g.standard_normal((n, ns, wc)).astype(np.float32)
+    ti, tp, tw = cu(feat).requires_grad_(True), cu(pos).requires_grad_(True), cu(w).requires_grad_(True)
+    out = po.aggregation(ti, tp, tw, cu(idx, torch.int32))
+    assert np.allclose(out.detach().cpu().numpy(), opo.aggregation(feat, pos, w, idx), atol=1e-4)
+    cot = g.standard_normal((n, c)).astype(np.float32)
+    (out * cu(cot)).sum().backward()
+    ri, rp, rw = (torch.tensor(x, requires_grad=True) for x in (feat, pos, w))
+    ro = ((ri[torch.as_tensor(idx)] + rp) * rw[:, :, torch.arange(c) % wc]).sum(1)
+    (ro * torch.tensor(cot)).sum().backward()
+    for a_, b_ in ((ti, ri), (tp, rp), (tw, rw)):
+        assert torch.allclose(a_.grad.cpu(), b_.grad, atol=1e-4)
+    # interpolation
+    xyz, off = data(6, (120, 80)); new_xyz, noff = data(7, (60, 40))
+    fin = g.standard_normal((200, c)).astype(np.float32)
+    tf = cu(fin).requires_grad_(True)
+    out = po.interpolation(cu(xyz), cu(new_xyz), tf, cu(off), cu(noff), 3)
+    ridx, rd2 = opo.knn_query(3, xyz, off, new_xyz, noff)
+    wgt = opo.interpolation_weights(np.sqrt(rd2))
+    assert np.allclose(out.detach().cpu().numpy(), opo.interpolation(fin, ridx, wgt), atol=1e-4)
+    out.sum().backward()
+    ref = np.zeros_like(fin); np.add.at(ref, ridx, np.repeat(wgt[:, :, None], c, 2))
+    assert np.allclose(tf.grad.cpu().numpy(), ref, atol=1e-4)
+
+
+def test_attention_relation_fusion_and_pointops2_steps():
+    from scenesplat_amd import pointops as po
+    g = np.random.default_rng(8)
+    n, m, h, c = 90, 400, 3, 8
+    q, k, v = (g.standard_normal((n, h, c)).astype(np.float32) for _ in range(3))
+    w = g.standard_normal(c).astype(np.float32)
+    it, ir = g.integers(0, n, m), g.integers(0, n, m)
+    tq, tk, tw = cu(q).requires_grad_(True), cu(k).requires_grad_(True), cu(w).requires_grad_(True)
+    out = po.attention_relation_step(tq, tk, tw, cu(it, torch.int32), cu(ir, torch.int32))
+    assert np.allclose(out.detach().cpu().numpy(), opo.attention_relation(q, k, w, it, ir), atol=1e-4)
+    cot = g.standard_normal((m, h)).astype(np.float32)
+    (out * cu(cot)).sum().backward()
+    rq, rk, rw = (torch.tensor(x, requires_grad=True) for x in (q, k, w))
+    ((rq[it] * rk[ir] * rw).sum(-1) * torch.tensor(cot)).sum().backward()
+    for a_, b_ in ((tq, rq), (tk, rk), (tw, rw)):
+        assert torch.allclose(a_.grad.cpu(), b_.grad, atol=2e-4)
+    # step1 (no channel weight) and step2 / fusion
+    out1 = po.attention_step1(cu(q), cu(k), cu(it, torch.int32), cu(ir, torch.int32))
+    assert np.allclose(out1.cpu().numpy(), opo.attention_relation(q, k, None, it, ir), atol=1e-4)
+    attn = g.standard_normal((m, h)).astype(np.float32)
+    ta, tv = cu(attn).requires_grad_(True), cu(v).requires_grad_(True)
+    out2 = po.attention_step2(ta, tv, cu(it, torch.int32), cu(ir, torch.int32))
+    assert np.allclose(out2.detach().cpu().numpy(), opo.attention_fusion(attn, v, it, ir, n), atol=1e-4)
+    cot = g.standard_normal((n, h, c)).astype(np.float32)
+    (out2 * cu(cot)).sum().backward()
+    ra, rv = torch.tensor(attn, requires_grad=True), torch.tensor(v, requires_grad=True)
+    ro = torch.zeros(n, h, c).index_add(0, torch.as_tensor(it), ra[:, :, None] * rv[ir])
+    (ro * torch.tensor(cot)).sum().backward()
+    assert torch.allclose(ta.grad.cpu(), ra.grad, atol=2e-4) and torch.allclose(tv.grad.cpu(), rv.grad, atol=2e-4)
+    # relative position encoding
+    L = 7
+    table = g.standard_normal((L, h, c, 3)).astype(np.float32)
+    rel = g.integers(0, L, (m, 3))
+    tq, tt = cu(q).requires_grad_(True), cu(table).requires_grad_(True)
+    o = po.dot_prod_with_idx(tq, cu(it, torch.int32), tt, cu(rel, torch.int32))
+    assert np.allclose(o.detach().cpu().numpy(), opo.rpe_dot_prod(q, it, table, rel), atol=1e-4)
+    o.sum().backward()
+    rq, rt = torch.tensor(q, requires_grad=True), torch.tensor(table, requires_grad=True)
+    sum((rq[it] * rt[rel[:, d], :, :, d]).sum() for d in range(3)).backward()
+    assert torch.allclose(tq.grad.cpu(), rq.grad, atol=2e-4) and torch.allclose(tt.grad.cpu(), rt.grad, atol=2e-4)
+    ta, tv, tt = cu(attn).requires_grad_(True), cu(v).requires_grad_(True), cu(table).requires_grad_(True)
+    o = po.attention_step2_with_rel_pos_value(ta, tv, cu(it, torch.int32), cu(ir, torch.int32), tt, cu(rel, torch.int32))
+    assert np.allclose(o.detach().cpu().numpy(), opo.rpe_attn_step2(attn, v, it, ir, table, rel, n), atol=1e-4)
+    (o * cu(cot)).sum().backward()
+    ra, rv, rt = (torch.tensor(x, requires_grad=True) for x in (attn, v, table))
+    tsum = sum(rt[rel[:, d], :, :, d] for d in range(3))
+    ro = torch.zeros(n, h, c).index_add(0, torch.as_tensor(it), ra[:, :, None] * (rv[ir] + tsum))
+    (ro * torch.tensor(cot)).sum().backward()
+    for a_, b_ in ((ta, ra), (tv, rv), (tt, rt)):
+        assert torch.allclose(a_.grad.cpu(), b_.grad, atol=3e-4)
+
+
+def test_pointgroup_ballquery_and_bfs_cluster():
+    from scenesplat_amd import pointops as po
+    xyz, off = data(9, (400, 250))
+    bidx = np.repeat([0, 1], [400, 250]); boff = np.array([0, 400, 650])
+    idx, start_len = po.ballquery_batch_p(cu(xyz), cu(bidx, torch.int32), cu(boff, torch.int32), 0.12, 2)   # forces one regrow
+    ridx, rsl = opo.ballquery_batch_p(xyz, bidx, boff, 0.12)
+    assert np.array_equal(start_len.cpu().numpy(), rsl) and np.array_equal(idx.cpu().numpy(), ridx)
+    labels = (xyz[:, 0] > 0.5).astype(np.int32)
+    cidx, coff = po.bfs_cluster(torch.as_tensor(labels), idx.cpu(), start_len.cpu(), 10)
+    ri, ro = opo.bfs_cluster(labels, ridx, rsl, 10)
+    assert np.array_equal(cidx.numpy(), ri) and np.array_equal(coff.numpy(), ro)
