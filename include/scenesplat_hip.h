@@ -95,6 +95,18 @@ int ss_subm_conv_fwd(const void* in, const void* weight, const float* bias, cons
 int ss_subm_conv_wgrad(const void* in, const void* dout, const int32_t* nbr, const int32_t* rowperm, float* dweight,
                        int64_t n, int cin, int cout, int taps, ss_stream_t stream);
 
+/* ---- fused residual add (+ DropPath row scale) + LayerNorm (ptv3:318-338 seams) ------------------------
+ * v = x + rowscale*y; xout = v (f32/bf16) [+ bf16 copy]; h = LN(v)*gamma+beta.  NULL = absent.  C % 4 == 0, C <= 1024. */
+int ss_add_layernorm_fwd(const void* x, int x_dtype, const void* y, int y_dtype, const float* rowscale,
+                         const float* gamma, const float* beta, float eps, void* xout, int xout_dtype, void* xcopy_bf16,
+                         void* h, int h_dtype, float* mean, float* rstd, int64_t n, int channels, ss_stream_t stream);
+int ss_add_layernorm_bwd_blocks(int64_t n);
+/* g_v = g_xout + g_xcopy + LN'(g_h); g_x = g_v; g_y = rowscale*g_v; dgamma/dbeta partials (nblocks, C) */
+int ss_add_layernorm_bwd(const void* g_xout, int g_xout_dtype, const void* g_xcopy, int g_xcopy_dtype, const void* g_h,
+                         int g_h_dtype, const void* v, int v_dtype, const float* mean, const float* rstd,
+                         const float* gamma, const float* rowscale, void* g_x, int g_x_dtype, void* g_y, int g_y_dtype,
+                         float* dgamma_part, float* dbeta_part, int64_t n, int channels, int nblocks, ss_stream_t stream);
+
 /* ---- row movement ------------------------------------------------------------------------ */
 int ss_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_dst, int64_t row_bytes, ss_stream_t stream);
 int ss_scatter_rows(const void* src, const int32_t* idx, void* dst, int64_t n_src, int64_t row_bytes, ss_stream_t stream);

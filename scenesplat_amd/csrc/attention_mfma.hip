@@ -72,8 +72,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {   // bijective: bloc
   return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
 }
 
-#define FA_THREADS 256
-#define FA_BQ 256
+// 8 waves per workgroup, each owning FA_NT = 2 sixteen-wide tiles (32 queries, or 32 keys in the
+// dK/dV kernel): ~100-130 VGPRs per wave so several waves share a SIMD and one wave's softmax VALU
+// work overlaps another's MFMAs (a 4-tile / 4-wave variant needed >256 registers and spent half
+// its instructions on v_accvgpr copies: 7.7k cycles per 64-key tile against 0.9k of MFMA).
+#define FA_NT 2
+#ifndef FA_WAVES
+#define FA_WAVES 4
+#endif
+#define FA_THREADS (64 * FA_WAVES)
+#define FA_WQ (16 * FA_NT)            // rows (queries / keys) per wave
+#define FA_BQ (FA_WQ * FA_WAVES)      // 256 rows per workgroup
 #define FA_BK 64
 
 // stage a 64-row K/V tile (rows gidx[p0+r0 .. +63], column block `colofs`) into registers
@@ -88,9 +97,11 @@ __device__ __forceinline__ void tile_load(uint4 (&reg)[NLD], const unsigned shor
     int second = c >= 64 * CH;
     int cc = second ? c - 64 * CH : c;
     int r = cc / CH, ch = cc - r * CH;
+    // rows past the window end are clamped to its last row: finite duplicates whose scores are masked
+    // (K) or multiplied by p = 0 (V), so no zero fill and no divergent branch
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (r0 + r < L) {
-      int64_t row = gidx[p0 + r0 + r];
+    if ((2 * 64 * CH) % FA_THREADS == 0 || c < 2 * 64 * CH) {
+      int64_t row = gidx[p0 + min(r0 + r, L - 1)];
       v = ld16(qkv + row * C3 + (second ? colofs_b : colofs_a) + ch * 8);
     }
     reg[i] = v;
@@ -101,12 +112,12 @@ __device__ __forceinline__ void tile_load(uint4 (&reg)[NLD], const unsigned shor
 // forward
 // =====================================================================================
 template <int D>
-__global__ void __launch_bounds__(FA_THREADS, (D <= 32 ? 2 : 1))
+__global__ void __launch_bounds__(FA_THREADS)
 k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restrict__ gidx,
                 const int32_t* __restrict__ sidx, const int32_t* __restrict__ win_start,
                 unsigned short* __restrict__ out, float* __restrict__ lse, int C, int H, float scale, int qchunks) {
   using A = ACfg<D>;
-  constexpr int NLD = (2 * 64 * A::CH) / FA_THREADS;     // 16-B loads per thread per K+V tile
+  constexpr int NLD = (2 * 64 * A::CH + FA_THREADS - 1) / FA_THREADS;     // 16-B loads per thread per K+V tile
   constexpr int KIMG = 64 * A::ROWB, VIMG = 64 * A::TRB;
   __shared__ __attribute__((aligned(16))) char smem[2 * (KIMG + VIMG)];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, g = lane >> 4;
@@ -127,11 +138,11 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
     }
   }
   // Q fragments (B operand of S^T = K Q^T): lane holds Q[q = lq][d = 32ks + 8g .. +7]
-  bf8_t qf[4][A::NKS];
-  int qslot[4];
+  bf8_t qf[FA_NT][A::NKS];
+  int qslot[FA_NT];
 #pragma unroll
-  for (int qt = 0; qt < 4; ++qt) {
-    int slot = q0 + wave * 64 + qt * 16 + lq;
+  for (int qt = 0; qt < FA_NT; ++qt) {
+    int slot = q0 + wave * FA_WQ + qt * 16 + lq;
     qslot[qt] = slot;
     int64_t row = slot < L ? gidx[p0 + slot] : -1;
 #pragma unroll
@@ -142,11 +153,15 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
       qf[qt][ks] = as_bf8(v);
     }
   }
-  float m[4], l[4];
-  f32x4_t o[A::NDT][4];
+  // row sums ride the matrix pipe: an extra A tile whose row 0 is all ones makes
+  // lsum[qt][0] (lane group 0) = sum_k P[k][q] of the same bf16-rounded P the PV product uses;
+  // the softmax is VALU-bound at d = 48, so 2 MFMAs per step are cheaper than 32 v_add per tile
+  const bf8_t ones = as_bf8(lq == 0 ? make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u) : make_uint4(0, 0, 0, 0));
+  float m[FA_NT];
+  f32x4_t o[A::NDT][FA_NT], lsum[FA_NT];
 #pragma unroll
-  for (int qt = 0; qt < 4; ++qt) {
-    m[qt] = -1e30f; l[qt] = 0.f;
+  for (int qt = 0; qt < FA_NT; ++qt) {
+    m[qt] = -1e30f; lsum[qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < A::NDT; ++dt) o[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
@@ -158,6 +173,7 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
       int second = c >= 64 * A::CH;
       int cc = second ? c - 64 * A::CH : c;
       int r = cc / A::CH, ch = cc - r * A::CH;
+      if (c >= 2 * 64 * A::CH) continue;
       if (second) *reinterpret_cast<uint4*>(Vbuf(b) + r * A::TRB + ch * 16) = stage[i];
       else *reinterpret_cast<uint4*>(Kbuf(b) + row_img_off<D>(r, ch)) = stage[i];
     }
@@ -170,16 +186,16 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
     const int b = t & 1, kv0 = t * FA_BK;
     if (t + 1 < ntiles) tile_load<D, NLD>(stage, qkv, gidx, p0, kv0 + FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
     // ---- S^T = K Q^T : s[kt][qt], rows = keys 16kt + 4g + r, col = query lq
-    f32x4_t s[4][4];
+    f32x4_t s[4][FA_NT];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-      for (int qt = 0; qt < 4; ++qt) s[kt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int qt = 0; qt < FA_NT; ++qt) s[kt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < A::NKS; ++ks) {
         bf8_t a = lds_b128(Kbuf(b), row_img_off<D>(16 * kt + lq, 4 * ks + g));
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) s[kt][qt] = MFMA16(a, qf[qt][ks], s[kt][qt]);
+        for (int qt = 0; qt < FA_NT; ++qt) s[kt][qt] = MFMA16(a, qf[qt][ks], s[kt][qt]);
       }
     }
     if (kv0 + FA_BK > L) {   // mask the keys past the window end (last tile only; wave-uniform)
@@ -189,12 +205,12 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
         for (int r = 0; r < 4; ++r)
           if (kv0 + 16 * kt + 4 * g + r >= L) {
 #pragma unroll
-            for (int qt = 0; qt < 4; ++qt) s[kt][qt][r] = -INFINITY;
+            for (int qt = 0; qt < FA_NT; ++qt) s[kt][qt][r] = -INFINITY;
           }
     }
     // ---- online softmax, lane-local per query column
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
+    for (int qt = 0; qt < FA_NT; ++qt) {
       float mx = s[0][qt][0];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
@@ -202,32 +218,37 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
       mx = xmax4(mx);
       float mn = fmaxf(m[qt], mx);
-      float alpha = __builtin_amdgcn_exp2f((m[qt] - mn) * c2);
+      // exact skip: when no lane's running max moved, alpha == 1 for the whole wave
+      if (__any(mn > m[qt])) {
+        float alpha = __builtin_amdgcn_exp2f((m[qt] - mn) * c2);
+        lsum[qt] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < A::NDT; ++dt) o[dt][qt] *= alpha;
+      }
       m[qt] = mn;
-      float mc = mn * c2, ps = 0.f;
+      float mc = mn * c2;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], c2, -mc));
-          s[kt][qt][r] = p; ps += p;
+          s[kt][qt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], c2, -mc));
         }
-      l[qt] = l[qt] * alpha + ps;
-#pragma unroll
-      for (int dt = 0; dt < A::NDT; ++dt) o[dt][qt] *= alpha;
     }
     // ---- O^T += V^T P^T ; k index (g, j) of step kk <-> key 32kk + 16(j>>2) + 4g + (j&3)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf8_t pf[4];
+      bf8_t pf[FA_NT];
 #pragma unroll
-      for (int qt = 0; qt < 4; ++qt) pf[qt] = pack8(s[2 * kk][qt], s[2 * kk + 1][qt]);
+      for (int qt = 0; qt < FA_NT; ++qt) {
+        pf[qt] = pack8(s[2 * kk][qt], s[2 * kk + 1][qt]);
+        lsum[qt] = MFMA16(ones, pf[qt], lsum[qt]);
+      }
       const char* vbase = Vbuf(b) + (32 * kk + 4 * g + (lq >> 2)) * A::TRB + (lq & 3) * 8;
 #pragma unroll
       for (int dt = 0; dt < A::NDT; ++dt) {
         bf8_t vf = cat_tr(lds_tr(vbase + dt * 32), lds_tr(vbase + 16 * A::TRB + dt * 32));
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) o[dt][qt] = MFMA16(vf, pf[qt], o[dt][qt]);
+        for (int qt = 0; qt < FA_NT; ++qt) o[dt][qt] = MFMA16(vf, pf[qt], o[dt][qt]);
       }
     }
     if (t + 1 < ntiles) stage_write(b ^ 1);
@@ -235,8 +256,8 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
   }
   // ---- epilogue
 #pragma unroll
-  for (int qt = 0; qt < 4; ++qt) {
-    float lt = xsum4(l[qt]);
+  for (int qt = 0; qt < FA_NT; ++qt) {
+    float lt = __shfl(lsum[qt][0], lq, 64);   // row 0 of the ones tile lives in lane group 0
     int slot = qslot[qt];
     if (slot < L) {
       if (g == 0) lse[(int64_t)(p0 + slot) * H + h] = m[qt] * scale + __logf(lt);
@@ -261,13 +282,13 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
 // dS^T = P^T o (dP^T - delta_q), dQ^T += K^T dS^T with K^T read transposed from a plain image.
 // =====================================================================================
 template <int D>
-__global__ void __launch_bounds__(FA_THREADS, 1)
+__global__ void __launch_bounds__(FA_THREADS)
 k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ dout,
                    const float* __restrict__ lse, const float* __restrict__ delta, const int32_t* __restrict__ gidx,
                    const int32_t* __restrict__ sidx, const int32_t* __restrict__ win_start,
                    unsigned short* __restrict__ dqkv, int C, int H, float scale, int qchunks) {
   using A = ACfg<D>;
-  constexpr int NLD = (2 * 64 * A::CH) / FA_THREADS;
+  constexpr int NLD = (2 * 64 * A::CH + FA_THREADS - 1) / FA_THREADS;
   constexpr int RIMG = 64 * A::ROWB, TIMG = 64 * A::TRB;
   constexpr int BUF = 2 * RIMG + TIMG;      // K row image, V row image, K tr image
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
@@ -286,12 +307,12 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
       *reinterpret_cast<uint4*>(base + row_img_off<D>(r, ch)) = make_uint4(0, 0, 0, 0);
     }
   }
-  bf8_t qf[4][A::NKS], gf[4][A::NKS];
-  float lse2[4], dl[4];
-  int32_t srow[4];
+  bf8_t qf[FA_NT][A::NKS], gf[FA_NT][A::NKS];
+  float lse2[FA_NT], dl[FA_NT];
+  int32_t srow[FA_NT];
 #pragma unroll
-  for (int qt = 0; qt < 4; ++qt) {
-    int slot = q0 + wave * 64 + qt * 16 + lq;
+  for (int qt = 0; qt < FA_NT; ++qt) {
+    int slot = q0 + wave * FA_WQ + qt * 16 + lq;
     bool ok = slot < L;
     int64_t row = ok ? gidx[p0 + slot] : -1;
     srow[qt] = ok ? sidx[p0 + slot] : -1;
@@ -306,9 +327,9 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
       qf[qt][ks] = as_bf8(v); gf[qt][ks] = as_bf8(u);
     }
   }
-  f32x4_t dq[A::NDT][4];
+  f32x4_t dq[A::NDT][FA_NT];
 #pragma unroll
-  for (int qt = 0; qt < 4; ++qt)
+  for (int qt = 0; qt < FA_NT; ++qt)
 #pragma unroll
     for (int dt = 0; dt < A::NDT; ++dt) dq[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   uint4 stage[NLD];
@@ -320,6 +341,7 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
       int second = c >= 64 * A::CH;
       int cc = second ? c - 64 * A::CH : c;
       int r = cc / A::CH, ch = cc - r * A::CH;
+      if (c >= 2 * 64 * A::CH) continue;
       if (second) *reinterpret_cast<uint4*>(base + RIMG + row_img_off<D>(r, ch)) = stage[i];
       else {
         *reinterpret_cast<uint4*>(base + row_img_off<D>(r, ch)) = stage[i];
@@ -335,17 +357,17 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
     const int b = t & 1, kv0 = t * FA_BK;
     const char* Kr = smem + b * BUF; const char* Vr = Kr + RIMG; const char* Kt = Kr + 2 * RIMG;
     if (t + 1 < ntiles) tile_load<D, NLD>(stage, qkv, gidx, p0, kv0 + FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
-    f32x4_t s[4][4], dp[4][4];
+    f32x4_t s[4][FA_NT], dp[4][FA_NT];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-      for (int qt = 0; qt < 4; ++qt) { s[kt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[kt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+      for (int qt = 0; qt < FA_NT; ++qt) { s[kt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[kt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int ks = 0; ks < A::NKS; ++ks) {
         int off = row_img_off<D>(16 * kt + lq, 4 * ks + g);
         bf8_t ka = lds_b128(Kr, off), va = lds_b128(Vr, off);
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
+        for (int qt = 0; qt < FA_NT; ++qt) {
           s[kt][qt] = MFMA16(ka, qf[qt][ks], s[kt][qt]);
           dp[kt][qt] = MFMA16(va, gf[qt][ks], dp[kt][qt]);
         }
@@ -355,7 +377,7 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int qt = 0; qt < 4; ++qt)
+      for (int qt = 0; qt < FA_NT; ++qt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], c2, -lse2[qt]));
@@ -365,22 +387,22 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
         }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf8_t df[4];
+      bf8_t df[FA_NT];
 #pragma unroll
-      for (int qt = 0; qt < 4; ++qt) df[qt] = pack8(s[2 * kk][qt], s[2 * kk + 1][qt]);
+      for (int qt = 0; qt < FA_NT; ++qt) df[qt] = pack8(s[2 * kk][qt], s[2 * kk + 1][qt]);
       const char* kbase = Kt + (32 * kk + 4 * g + (lq >> 2)) * A::TRB + (lq & 3) * 8;
 #pragma unroll
       for (int dt = 0; dt < A::NDT; ++dt) {
         bf8_t kf = cat_tr(lds_tr(kbase + dt * 32), lds_tr(kbase + 16 * A::TRB + dt * 32));
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) dq[dt][qt] = MFMA16(kf, df[qt], dq[dt][qt]);
+        for (int qt = 0; qt < FA_NT; ++qt) dq[dt][qt] = MFMA16(kf, df[qt], dq[dt][qt]);
       }
     }
     if (t + 1 < ntiles) stage_write(b ^ 1);
     __syncthreads();
   }
 #pragma unroll
-  for (int qt = 0; qt < 4; ++qt) {
+  for (int qt = 0; qt < FA_NT; ++qt) {
     if (srow[qt] >= 0) {
       unsigned short* op = dqkv + (int64_t)srow[qt] * C3 + h * D + 4 * g;
 #pragma unroll
@@ -401,7 +423,7 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
 // =====================================================================================
 #define FA_BQ2 32
 template <int D>
-__global__ void __launch_bounds__(FA_THREADS, 1)
+__global__ void __launch_bounds__(FA_THREADS)
 k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ dout,
                     const float* __restrict__ lse, const float* __restrict__ delta, const int32_t* __restrict__ gidx,
                     const int32_t* __restrict__ sidx, const int32_t* __restrict__ win_start,
@@ -417,7 +439,7 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int kc = lid % kchunks; const int t_ = lid / kchunks; const int h = t_ % H; const int w = t_ / H;
   const int p0 = win_start[w], L = win_start[w + 1] - p0;
-  const int k0 = kc * 256;
+  const int k0 = kc * FA_BQ;
   if (k0 >= L) return;
   const int64_t C3 = 3 * (int64_t)C;
   const float c2 = scale * 1.44269504088896340736f;
@@ -429,11 +451,11 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
     }
   }
   // K / V fragments as B operands: lane holds K[key = lq][d = 32ks + 8g ..]
-  bf8_t kf[4][A::NKS], vf[4][A::NKS];
-  int kslot[4];
+  bf8_t kf[FA_NT][A::NKS], vf[FA_NT][A::NKS];
+  int kslot[FA_NT];
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt) {
-    int slot = k0 + wave * 64 + kt * 16 + lq;
+  for (int kt = 0; kt < FA_NT; ++kt) {
+    int slot = k0 + wave * FA_WQ + kt * 16 + lq;
     kslot[kt] = slot;
     int64_t row = slot < L ? gidx[p0 + slot] : -1;
 #pragma unroll
@@ -444,9 +466,9 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
       kf[kt][ks] = as_bf8(a); vf[kt][ks] = as_bf8(b);
     }
   }
-  f32x4_t dk[A::NDT][4], dv[A::NDT][4];
+  f32x4_t dk[A::NDT][FA_NT], dv[A::NDT][FA_NT];
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt)
+  for (int kt = 0; kt < FA_NT; ++kt)
 #pragma unroll
     for (int dt = 0; dt < A::NDT; ++dt) { dk[dt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   uint4 stage[NLD];
@@ -501,17 +523,17 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
     const float* fl = reinterpret_cast<const float*>(Qr + 2 * RIMG + 2 * TIMG);
     if (t + 1 < ntiles) stage_load((t + 1) * FA_BQ2);
     // S[q][key], dP[q][key]: rows = queries 16qt + 4g + r, col = key lq (tile kt)
-    f32x4_t s[2][4], dp[2][4];
+    f32x4_t s[2][FA_NT], dp[2][FA_NT];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) { s[qt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[qt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+      for (int kt = 0; kt < FA_NT; ++kt) { s[qt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dp[qt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int ks = 0; ks < A::NKS; ++ks) {
         int off = row_img_off<D>(16 * qt + lq, 4 * ks + g);
         bf8_t qa = lds_b128(Qr, off), ga = lds_b128(Gr, off);
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < FA_NT; ++kt) {
           s[qt][kt] = MFMA16(qa, kf[kt][ks], s[qt][kt]);
           dp[qt][kt] = MFMA16(ga, vf[kt][ks], dp[qt][kt]);
         }
@@ -523,7 +545,7 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
       for (int r = 0; r < 4; ++r) {
         float l2 = fl[16 * qt + 4 * g + r], dd = fl[FA_BQ2 + 16 * qt + 4 * g + r];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < FA_NT; ++kt) {
           float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][kt][r], c2, -l2));
           s[qt][kt][r] = p;
           dp[qt][kt][r] = p * (dp[qt][kt][r] - dd);
@@ -533,15 +555,15 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
     {
       const char* gbase = Gt + (4 * g + (lq >> 2)) * A::TRB + (lq & 3) * 8;
       const char* qbase = Qt + (4 * g + (lq >> 2)) * A::TRB + (lq & 3) * 8;
-      bf8_t pf[4], df[4];
+      bf8_t pf[FA_NT], df[FA_NT];
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) { pf[kt] = pack8(s[0][kt], s[1][kt]); df[kt] = pack8(dp[0][kt], dp[1][kt]); }
+      for (int kt = 0; kt < FA_NT; ++kt) { pf[kt] = pack8(s[0][kt], s[1][kt]); df[kt] = pack8(dp[0][kt], dp[1][kt]); }
 #pragma unroll
       for (int dt = 0; dt < A::NDT; ++dt) {
         bf8_t ga = cat_tr(lds_tr(gbase + dt * 32), lds_tr(gbase + 16 * A::TRB + dt * 32));
         bf8_t qa = cat_tr(lds_tr(qbase + dt * 32), lds_tr(qbase + 16 * A::TRB + dt * 32));
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int kt = 0; kt < FA_NT; ++kt) {
           dv[dt][kt] = MFMA16(ga, pf[kt], dv[dt][kt]);
           dk[dt][kt] = MFMA16(qa, df[kt], dk[dt][kt]);
         }
@@ -551,7 +573,7 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
     __syncthreads();
   }
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt) {
+  for (int kt = 0; kt < FA_NT; ++kt) {
     int slot = kslot[kt];
     if (slot < L) {
       int32_t sr = sidx[p0 + slot];
@@ -597,7 +619,7 @@ int ss_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const 
                      int C, int H, float scale, hipStream_t st) {
   const int D = C / H;
   if ((C & 7) || max_window <= 0) return SS_ERR_ARG;
-  const int chunks = (max_window + 255) / 256;
+  const int chunks = (max_window + FA_BQ - 1) / FA_BQ;
   dim3 g((unsigned)(W * H * chunks)), b(FA_THREADS);
   const unsigned short* q = (const unsigned short*)qkv; const unsigned short* go = (const unsigned short*)dout;
   unsigned short* dq = (unsigned short*)dqkv; unsigned short* ex = (unsigned short*)extra;

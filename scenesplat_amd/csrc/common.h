@@ -38,8 +38,12 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
   __hip_bfloat16 b = __float2bfloat16(f);
   return *reinterpret_cast<unsigned short*>(&b);
 }
+// two f32 -> packed bf16x2 with ONE v_cvt_pk_bf16_f32 (RNE; NaN stays NaN)
+typedef __attribute__((ext_vector_type(2))) float ss_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 ss_bf16x2_t;
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+  ss_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, ss_bf16x2_t));
 }
 
 template <typename T> struct ElemIO;

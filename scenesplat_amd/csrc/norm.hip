@@ -1,0 +1,202 @@
+// Fused residual-add (+ DropPath row scale) + LayerNorm, forward and backward (gfx950, HBM-bound).
+// One pass per pre-norm seam of a PTv3 Block (ptv3:318-338) instead of PyTorch's separate
+// add / cast / layer_norm / layer_norm-backward / cast kernels:
+//     v     = x + rowscale * y          (y, rowscale optional)
+//     xout  = v                         (fp32 residual stream; optional extra bf16 copy for the next conv)
+//     h     = LN(v) * gamma + beta      (optional; written in bf16 for the following GEMM, or fp32)
+// backward:  g_v = g_xout + LN'(g_h);  g_x = g_v;  g_y = rowscale * g_v;  dgamma/dbeta as per-block
+// partial sums (reduced by the caller), fp32 statistics throughout.
+// One wave per row, 4 elements per lane per step (16-byte fp32 / 8-byte bf16 accesses, fully
+// coalesced 1 KiB / 512 B per wave instruction); the row lives in registers between the two passes.
+#include "common.h"
+#include "../../include/scenesplat_hip.h"
+
+#define LN_THREADS 256
+#define LN_MAXIT 4   // C <= 1024
+
+__device__ __forceinline__ float4 ln_ld4(const void* p, int dtype, int64_t idx) {
+  if (dtype == SS_F32) return *reinterpret_cast<const float4*>((const float*)p + idx);
+  uint2 u = *reinterpret_cast<const uint2*>((const unsigned short*)p + idx);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void ln_st4(void* p, int dtype, int64_t idx, float4 v) {
+  if (dtype == SS_F32) { *reinterpret_cast<float4*>((float*)p + idx) = v; return; }
+  uint2 u; u.x = pack_bf16x2(v.x, v.y); u.y = pack_bf16x2(v.z, v.w);
+  *reinterpret_cast<uint2*>((unsigned short*)p + idx) = u;
+}
+
+template <int IT>
+__global__ void __launch_bounds__(LN_THREADS)
+k_add_ln_fwd(const void* __restrict__ x, int x_dt, const void* __restrict__ y, int y_dt, const float* __restrict__ rowscale,
+             const float* __restrict__ gamma, const float* __restrict__ beta, float eps, void* __restrict__ xout, int xout_dt,
+             void* __restrict__ xcopy, void* __restrict__ h, int h_dt, float* __restrict__ mean, float* __restrict__ rstd,
+             int64_t n, int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float rs = rowscale ? rowscale[row] : 1.f;
+  float4 v[IT];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int j = i * 256 + lane * 4;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < C) {
+      float4 a = ln_ld4(x, x_dt, row * C + j);
+      if (y) { float4 b = ln_ld4(y, y_dt, row * C + j); a.x += rs * b.x; a.y += rs * b.y; a.z += rs * b.z; a.w += rs * b.w; }
+      v[i] = a;
+      if (xout) ln_st4(xout, xout_dt, row * C + j, a);
+      if (xcopy) ln_st4(xcopy, SS_BF16, row * C + j, a);
+      sum += a.x + a.y + a.z + a.w;
+    }
+  }
+  if (!gamma) return;
+  const float mu = wave_reduce_sum(sum) / C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int j = i * 256 + lane * 4;
+    if (j < C) {
+      float dx = v[i].x - mu, dy = v[i].y - mu, dz = v[i].z - mu, dw = v[i].w - mu;
+      sq += dx * dx + dy * dy + dz * dz + dw * dw;
+    }
+  }
+  const float r = rsqrtf(wave_reduce_sum(sq) / C + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = r; }
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int j = i * 256 + lane * 4;
+    if (j < C) {
+      float4 g = *reinterpret_cast<const float4*>(gamma + j), b = *reinterpret_cast<const float4*>(beta + j);
+      float4 o = make_float4((v[i].x - mu) * r * g.x + b.x, (v[i].y - mu) * r * g.y + b.y, (v[i].z - mu) * r * g.z + b.z,
+                             (v[i].w - mu) * r * g.w + b.w);
+      ln_st4(h, h_dt, row * C + j, o);
+    }
+  }
+}
+
+template <int IT>
+__global__ void __launch_bounds__(LN_THREADS)
+k_add_ln_bwd(const void* __restrict__ g_xout, int gxo_dt, const void* __restrict__ g_xcopy, int gxc_dt,
+             const void* __restrict__ g_h, int gh_dt,
+             const void* __restrict__ v_in, int v_dt, const float* __restrict__ mean, const float* __restrict__ rstd,
+             const float* __restrict__ gamma, const float* __restrict__ rowscale, void* __restrict__ g_x, int gx_dt,
+             void* __restrict__ g_y, int gy_dt, float* __restrict__ dgamma_part, float* __restrict__ dbeta_part, int64_t n,
+             int C) {
+  __shared__ float red[2][LN_THREADS / 64][LN_MAXIT * 256 / 64][64];   // [gamma|beta][wave][i*4+e][lane] -- only IT slices used
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int waves_total = gridDim.x * (LN_THREADS / 64);
+  const bool ln = g_h != nullptr;
+  float4 dg[IT], db[IT], gm[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f); db[i] = dg[i]; gm[i] = dg[i];
+    int j = i * 256 + lane * 4;
+    if (ln && j < C) gm[i] = *reinterpret_cast<const float4*>(gamma + j);
+  }
+  for (int64_t row = (int64_t)blockIdx.x * (LN_THREADS / 64) + wave; row < n; row += waves_total) {
+    float4 gv[IT];
+    if (ln) {
+      const float mu = mean[row], r = rstd[row];
+      float4 xh[IT], gy[IT];
+      float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        int j = i * 256 + lane * 4;
+        xh[i] = make_float4(0.f, 0.f, 0.f, 0.f); gy[i] = xh[i];
+        if (j < C) {
+          float4 a = ln_ld4(v_in, v_dt, row * C + j), g = ln_ld4(g_h, gh_dt, row * C + j);
+          xh[i] = make_float4((a.x - mu) * r, (a.y - mu) * r, (a.z - mu) * r, (a.w - mu) * r);
+          gy[i] = make_float4(g.x * gm[i].x, g.y * gm[i].y, g.z * gm[i].z, g.w * gm[i].w);
+          c1 += gy[i].x + gy[i].y + gy[i].z + gy[i].w;
+          c2 += gy[i].x * xh[i].x + gy[i].y * xh[i].y + gy[i].z * xh[i].z + gy[i].w * xh[i].w;
+          dg[i].x += g.x * xh[i].x; dg[i].y += g.y * xh[i].y; dg[i].z += g.z * xh[i].z; dg[i].w += g.w * xh[i].w;
+          db[i].x += g.x; db[i].y += g.y; db[i].z += g.z; db[i].w += g.w;
+        }
+      }
+      c1 = wave_reduce_sum(c1) / C; c2 = wave_reduce_sum(c2) / C;
+#pragma unroll
+      for (int i = 0; i < IT; ++i)
+        gv[i] = make_float4(r * (gy[i].x - c1 - xh[i].x * c2), r * (gy[i].y - c1 - xh[i].y * c2),
+                            r * (gy[i].z - c1 - xh[i].z * c2), r * (gy[i].w - c1 - xh[i].w * c2));
+    } else {
+#pragma unroll
+      for (int i = 0; i < IT; ++i) gv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float rs = rowscale ? rowscale[row] : 1.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int j = i * 256 + lane * 4;
+      if (j < C) {
+        if (g_xout) { float4 e = ln_ld4(g_xout, gxo_dt, row * C + j); gv[i].x += e.x; gv[i].y += e.y; gv[i].z += e.z; gv[i].w += e.w; }
+        if (g_xcopy) { float4 e = ln_ld4(g_xcopy, gxc_dt, row * C + j); gv[i].x += e.x; gv[i].y += e.y; gv[i].z += e.z; gv[i].w += e.w; }
+        if (g_x) ln_st4(g_x, gx_dt, row * C + j, gv[i]);
+        if (g_y) ln_st4(g_y, gy_dt, row * C + j, make_float4(rs * gv[i].x, rs * gv[i].y, rs * gv[i].z, rs * gv[i].w));
+      }
+    }
+  }
+  if (!ln) return;
+  // block reduction of the per-wave column partials, then one row of partials per block
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    red[0][wave][i * 4 + 0][lane] = dg[i].x; red[0][wave][i * 4 + 1][lane] = dg[i].y;
+    red[0][wave][i * 4 + 2][lane] = dg[i].z; red[0][wave][i * 4 + 3][lane] = dg[i].w;
+    red[1][wave][i * 4 + 0][lane] = db[i].x; red[1][wave][i * 4 + 1][lane] = db[i].y;
+    red[1][wave][i * 4 + 2][lane] = db[i].z; red[1][wave][i * 4 + 3][lane] = db[i].w;
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int j = i * 256 + lane * 4 + e;
+        if (j < C) {
+          float a = 0.f, b = 0.f;
+          for (int w = 0; w < LN_THREADS / 64; ++w) { a += red[0][w][i * 4 + e][lane]; b += red[1][w][i * 4 + e][lane]; }
+          dgamma_part[(int64_t)blockIdx.x * C + j] = a;
+          dbeta_part[(int64_t)blockIdx.x * C + j] = b;
+        }
+      }
+  }
+}
+
+extern "C" int ss_add_layernorm_fwd(const void* x, int x_dtype, const void* y, int y_dtype, const float* rowscale,
+                                    const float* gamma, const float* beta, float eps, void* xout, int xout_dtype,
+                                    void* xcopy_bf16, void* h, int h_dtype, float* mean, float* rstd, int64_t n, int channels,
+                                    hipStream_t stream) {
+  if (n < 0 || channels <= 0 || (channels & 3) || channels > LN_MAXIT * 256) return SS_ERR_ARG;
+  if (gamma && (!beta || !h || !mean || !rstd)) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  dim3 g(ss_div_up(n, LN_THREADS / 64)), b(LN_THREADS);
+  const int it = (channels + 255) / 256;
+#define SS_LN_FWD(ITN) SS_LAUNCH(k_add_ln_fwd<ITN>, g, b, 0, stream, x, x_dtype, y, y_dtype, rowscale, gamma, beta, eps, xout, xout_dtype, xcopy_bf16, h, h_dtype, mean, rstd, n, channels)
+  switch (it) { case 1: SS_LN_FWD(1); break; case 2: SS_LN_FWD(2); break; case 3: SS_LN_FWD(3); break; default: SS_LN_FWD(4); break; }
+#undef SS_LN_FWD
+  return SS_OK;
+}
+
+extern "C" int ss_add_layernorm_bwd_blocks(int64_t n) {
+  int64_t b = (n + (LN_THREADS / 64) * 8 - 1) / ((LN_THREADS / 64) * 8);   // >= 8 rows per wave
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" int ss_add_layernorm_bwd(const void* g_xout, int g_xout_dtype, const void* g_xcopy, int g_xcopy_dtype,
+                                    const void* g_h, int g_h_dtype, const void* v,
+                                    int v_dtype, const float* mean, const float* rstd, const float* gamma,
+                                    const float* rowscale, void* g_x, int g_x_dtype, void* g_y, int g_y_dtype,
+                                    float* dgamma_part, float* dbeta_part, int64_t n, int channels, int nblocks,
+                                    hipStream_t stream) {
+  if (n < 0 || channels <= 0 || (channels & 3) || channels > LN_MAXIT * 256 || nblocks < 1) return SS_ERR_ARG;
+  if (g_h && (!v || !mean || !rstd || !gamma || !dgamma_part || !dbeta_part)) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  dim3 g(nblocks), b(LN_THREADS);
+  const int it = (channels + 255) / 256;
+#define SS_LN_BWD(ITN) SS_LAUNCH(k_add_ln_bwd<ITN>, g, b, 0, stream, g_xout, g_xout_dtype, g_xcopy, g_xcopy_dtype, g_h, g_h_dtype, v, v_dtype, mean, rstd, gamma, rowscale, g_x, g_x_dtype, g_y, g_y_dtype, dgamma_part, dbeta_part, n, channels)
+  switch (it) { case 1: SS_LN_BWD(1); break; case 2: SS_LN_BWD(2); break; case 3: SS_LN_BWD(3); break; default: SS_LN_BWD(4); break; }
+#undef SS_LN_BWD
+  return SS_OK;
+}

@@ -167,3 +167,59 @@ def subm_conv3d(feat, weight, bias, nbr, has_dup=False, compute_dtype=torch.floa
     if compute_dtype == torch.bfloat16 and not has_dup and weight.shape[0] % 8 == 0:
         return _SubMConv3dFused.apply(feat, weight, bias, nbr, rowperm)
     return _SubMConv3d.apply(feat, weight, bias, nbr, has_dup, compute_dtype)
+
+
+class _LayerNorm(torch.autograd.Function):
+    """h = LN(x) in one pass, bf16 or fp32 out (csrc/norm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, out_dtype):
+        x = x.contiguous()
+        _, _, h, mean, rstd = nv.add_layernorm_fwd(x, None, None, gamma.float().contiguous(), beta.float().contiguous(), eps,
+                                                   False, False, out_dtype)
+        ctx.save_for_backward(x, mean, rstd, gamma)
+        return h
+
+    @staticmethod
+    def backward(ctx, g_h):
+        x, mean, rstd, gamma = ctx.saved_tensors
+        g_x, _, dg, db = nv.add_layernorm_bwd(None, None, g_h.contiguous(), x, mean, rstd, gamma.float().contiguous(), None,
+                                              x.dtype, None)
+        return g_x, dg.to(gamma.dtype), db.to(gamma.dtype), None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5, out_dtype=None):
+    return _LayerNorm.apply(x, gamma, beta, eps, out_dtype or x.dtype)
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    """(x, y) -> xout = x + rowscale*y [fp32], h = LN(xout) [optional], xcopy = bf16(xout) [optional]."""
+
+    @staticmethod
+    def forward(ctx, x, y, rowscale, gamma, beta, eps, want_copy, h_dtype):
+        x, y = x.contiguous(), y.contiguous()
+        g32 = gamma.float().contiguous() if gamma is not None else None
+        b32 = beta.float().contiguous() if beta is not None else None
+        xout, xcopy, h, mean, rstd = nv.add_layernorm_fwd(x, y, rowscale, g32, b32, eps, True, want_copy, h_dtype)
+        ctx.save_for_backward(xout, mean, rstd, g32, rowscale)
+        ctx.meta = (x.dtype, y.dtype, gamma.dtype if gamma is not None else None)
+        ctx.set_materialize_grads(False)
+        return xout, h, xcopy
+
+    @staticmethod
+    def backward(ctx, g_xout, g_h, g_xcopy):
+        xout, mean, rstd, g32, rowscale = ctx.saved_tensors
+        x_dt, y_dt, g_dt = ctx.meta
+        g_xout = g_xout.contiguous() if g_xout is not None else None
+        g_h = g_h.contiguous() if g_h is not None else None
+        g_xcopy = g_xcopy.contiguous() if g_xcopy is not None else None
+        if g_xout is None and g_h is None and g_xcopy is None:
+            return None, None, None, None, None, None, None, None
+        g_x, g_y, dg, db = nv.add_layernorm_bwd(g_xout, g_xcopy, g_h, xout, mean, rstd, g32, rowscale, x_dt, y_dt)
+        return (g_x, g_y, None, dg.to(g_dt) if dg is not None else None, db.to(g_dt) if db is not None else None,
+                None, None, None)
+
+
+def add_layer_norm(x, y, rowscale=None, gamma=None, beta=None, eps=1e-5, want_copy=False, h_dtype=torch.float32):
+    """Fused residual seam: returns (xout fp32, h or None, bf16 copy of xout or None)."""
+    return _AddLayerNorm.apply(x, y, rowscale, gamma, beta, eps, want_copy, h_dtype)

@@ -186,6 +186,55 @@ def subm_conv_wgrad(x, dout, nbr, rowperm):
     return dw
 
 
+# ---- fused add + layernorm ----------------------------------------------------------------------
+def _dt(t):
+    return dtype_code(t) if t is not None else 0
+
+
+def add_layernorm_fwd(x, y, rowscale, gamma, beta, eps, want_xout, want_copy, h_dtype):
+    """v = x + rowscale*y -> (xout f32 | None, xcopy bf16 | None, h | None, mean, rstd)."""
+    n, C = x.shape
+    _req(x, None, "x")
+    if y is not None:
+        _req(y, None, "y", (n, C))
+    if rowscale is not None:
+        _req(rowscale, torch.float32, "rowscale", (n,))
+    dev = x.device
+    xout = torch.empty((n, C), dtype=torch.float32, device=dev) if want_xout else None
+    xcopy = torch.empty((n, C), dtype=torch.bfloat16, device=dev) if want_copy else None
+    h = mean = rstd = None
+    if gamma is not None:
+        _req(gamma, torch.float32, "gamma", (C,)); _req(beta, torch.float32, "beta", (C,))
+        h = torch.empty((n, C), dtype=h_dtype, device=dev)
+        mean = torch.empty(n, dtype=torch.float32, device=dev); rstd = torch.empty(n, dtype=torch.float32, device=dev)
+    check(lib().ss_add_layernorm_fwd(_p(x), _dt(x), _p(y), _dt(y), _p(rowscale), _p(gamma), _p(beta), float(eps), _p(xout), F32,
+                                     _p(xcopy), _p(h), _dt(h), _p(mean), _p(rstd), n, C, _stream()), "ss_add_layernorm_fwd")
+    return xout, xcopy, h, mean, rstd
+
+
+def add_layernorm_bwd(g_xout, g_xcopy, g_h, v, mean, rstd, gamma, rowscale, gx_dtype, gy_dtype):
+    """-> (g_x | None, g_y | None, dgamma | None, dbeta | None)"""
+    ref = g_h if g_h is not None else (g_xout if g_xout is not None else g_xcopy)
+    n, C = ref.shape
+    dev = ref.device
+    for t, nm in ((g_xout, "g_xout"), (g_xcopy, "g_xcopy"), (g_h, "g_h")):
+        if t is not None:
+            _req(t, None, nm, (n, C))
+    g_x = torch.empty((n, C), dtype=gx_dtype, device=dev) if gx_dtype is not None else None
+    g_y = torch.empty((n, C), dtype=gy_dtype, device=dev) if gy_dtype is not None else None
+    nb = lib().ss_add_layernorm_bwd_blocks(n)
+    dgp = dbp = None
+    if g_h is not None:
+        dgp = torch.empty((nb, C), dtype=torch.float32, device=dev); dbp = torch.empty((nb, C), dtype=torch.float32, device=dev)
+        _req(v, None, "v", (n, C))
+    check(lib().ss_add_layernorm_bwd(_p(g_xout), _dt(g_xout), _p(g_xcopy), _dt(g_xcopy), _p(g_h), _dt(g_h), _p(v), _dt(v),
+                                     _p(mean), _p(rstd), _p(gamma), _p(rowscale), _p(g_x), _dt(g_x), _p(g_y), _dt(g_y),
+                                     _p(dgp), _p(dbp), n, C, nb, _stream()), "ss_add_layernorm_bwd")
+    if g_h is not None:
+        return g_x, g_y, dgp.sum(0), dbp.sum(0)
+    return g_x, g_y, None, None
+
+
 # ---- rows ------------------------------------------------------------------------------------
 def gather_rows(src, idx, out=None):
     """out[i] = src[idx[i]] (zero row where idx < 0).  src (m, C)."""

@@ -124,20 +124,33 @@ class Block(PointModule):
         self.mlp = nn.Sequential(MLP(channels, int(channels * mlp_ratio), channels, act_layer, proj_drop))
         self.drop_path = nn.Sequential(DropPath(drop_path) if drop_path > 0.0 else nn.Identity())
 
-    def forward(self, x, conv_in, level):
-        """x: Point.feat; conv_in: sparse_conv_feat.features (differs from x only in the first
-        decoder block of a stage)."""
+    def forward(self, x, conv_in, level, want_copy=False):
+        """x: Point.feat; conv_in: sparse_conv_feat.features (differs from x only in the first decoder
+        block of a stage).  Returns (x_out, bf16 copy of x_out or None).  The three residual seams run as
+        fused add + DropPath-scale + LayerNorm kernels (csrc/norm.hip)."""
+        if not self.pre_norm:
+            return self._forward_post_norm(x, conv_in, level), None
+        hdt = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+        ln0, ln1, ln2 = self.cpe[2], self.norm1[0], self.norm2[0]
+        t = self.cpe[1](self.cpe[0](conv_in, level))
+        t = SF.layer_norm(t, ln0.weight, ln0.bias, ln0.eps)
+        x, h, _ = SF.add_layer_norm(x, t, None, ln1.weight, ln1.bias, ln1.eps, False, hdt)
+        x, h, _ = SF.add_layer_norm(x, self.attn(h, level), self._row_scale(x), ln2.weight, ln2.bias, ln2.eps, False, hdt)
+        x, _, xb = SF.add_layer_norm(x, self.mlp(h), self._row_scale(x), None, None, 0.0, want_copy, hdt)
+        return x, xb
+
+    def _row_scale(self, x):
+        dp = self.drop_path[0]
+        if not isinstance(dp, DropPath) or dp.p == 0.0 or not self.training:
+            return None
+        keep = 1.0 - dp.p
+        return x.new_empty(x.shape[0], dtype=torch.float32).bernoulli_(keep).div_(keep)
+
+    def _forward_post_norm(self, x, conv_in, level):
         c = self.cpe[0](conv_in, level)
         x = x + self.cpe[2](self.cpe[1](c))
-        h = self.norm1(x) if self.pre_norm else x
-        x = x + self.drop_path(self.attn(h, level))
-        if not self.pre_norm:
-            x = self.norm1(x)
-        h = self.norm2(x) if self.pre_norm else x
-        x = x + self.drop_path(self.mlp(h))
-        if not self.pre_norm:
-            x = self.norm2(x)
-        return x
+        x = self.norm1(x + self.drop_path(self.attn(x, level)))
+        return self.norm2(x + self.drop_path(self.mlp(x)))
 
 
 class SerializedPooling(PointModule):
@@ -285,6 +298,8 @@ class PointTransformerV3(PointModule):
             offset = point["offset"]
         else:
             offset = point["offset"]  # derived lazily from batch
+        # the fused conv consumes bf16: let each block hand the next one a bf16 copy of the residual stream
+        self._want_copy = (RUNTIME["conv_dtype"] == torch.bfloat16)
         plan = build_plan(point["grid_coord"], offset, self.order, self.stride,
                           perms if perms is not None else self.draw_perms())
         levels = plan.levels
@@ -295,15 +310,18 @@ class PointTransformerV3(PointModule):
             if s > 0:
                 skips.append(x)
                 x = enc.down(x, levels[s])
+            xb = None
             for i in range(self.enc_depths[s]):
-                x = getattr(enc, f"block{i}")(x, x, levels[s])
+                x, xb = getattr(enc, f"block{i}")(x, x if xb is None else xb, levels[s], self._want_copy and i + 1 < self.enc_depths[s])
         lv = self.num_stages - 1
         if not self.cls_mode:
             for s in reversed(range(self.num_stages - 1)):
                 dec = getattr(self.dec, f"dec{s}")
                 x, conv_in = dec.up(x, skips[s], levels[s + 1])
+                xb = None
                 for i in range(self.dec_depths[s]):
-                    x = getattr(dec, f"block{i}")(x, conv_in if i == 0 else x, levels[s])
+                    x, xb = getattr(dec, f"block{i}")(x, conv_in if i == 0 else (x if xb is None else xb), levels[s],
+                                                      self._want_copy and i + 1 < self.dec_depths[s])
             lv = 0
         out = Point(feat=x, plan=plan, level=lv)
         for k in ("coord", "grid_coord", "offset"):

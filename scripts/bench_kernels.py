@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""Isolated timings of the hot HIP kernels at the dec0 shapes of room-102400 (GPU box helper)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from scenesplat_amd import native as nv
+from scenesplat_amd.plan import build_plan
+from scenesplat_amd.synthetic import room_chunk
+
+
+def ev(fn, iters=10, warm=3):
+    for _ in range(warm): fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    which = sys.argv[1:] or ["attn", "conv"]
+    data = room_chunk(256, 0, lang_dim=0)
+    plan = build_plan(data["grid_coord"].cuda(), data["offset"].cuda(), ("z", "z-trans", "hilbert", "hilbert-trans"), (2, 2, 2))
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for li, (C, H) in enumerate([(768, 16), (512, 16), (256, 16)]):
+        lv = plan.levels[li]
+        n = lv.n
+        if "attn" in which:
+            win = lv.window(0, 1024)
+            qkv = torch.randn(n, 3 * C, device="cuda", generator=g).to(torch.bfloat16)
+            dout = torch.randn(n, C, device="cuda", generator=g).to(torch.bfloat16)
+            sc = (C // H) ** -0.5
+            o, lse = nv.window_attn_fwd(qkv, win, H, sc, nv.ATTN_MFMA)
+            tf = ev(lambda: nv.window_attn_fwd(qkv, win, H, sc, nv.ATTN_MFMA))
+            tb = ev(lambda: nv.window_attn_bwd(qkv, o, dout, lse, win, H, sc, nv.ATTN_MFMA))
+            fl = win.num_windows * H * 4.0 * 1024 * 1024 * (C // H)
+            print(f"attn L{li} n={n} C={C} d={C//H}: fwd {tf:.3f} ms ({fl/tf/1e9:.0f} TF/s)  bwd {tb:.3f} ms ({2.5*fl/tb/1e9:.0f} TF/s alg)", flush=True)
+        if "conv" in which:
+            nbr = lv.neighbors(3); perm = lv.conv_rowperm()
+            x = torch.randn(n, C, device="cuda", generator=g).to(torch.bfloat16)
+            w = (torch.randn(C, 27, C, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+            gout = torch.randn(n, C, device="cuda", generator=g).to(torch.bfloat16)
+            act = (nbr >= 0).float().sum().item() / n
+            tf = ev(lambda: nv.subm_conv_fwd(x, w, None, nbr, perm), 5, 2)
+            tw = ev(lambda: nv.subm_conv_wgrad(x, gout, nbr, perm), 5, 2)
+            fl = 2.0 * n * act * C * C
+            print(f"conv L{li} n={n} C={C} taps/site={act:.2f}: fwd {tf:.3f} ms ({fl/tf/1e9:.0f} TF/s)  wgrad {tw:.3f} ms ({fl/tw/1e9:.0f} TF/s)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

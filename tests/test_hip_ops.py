@@ -225,3 +225,47 @@ def test_window_attention_mfma_matches_simt_fwd_bwd(H, d, K, counts):
         rel = (a - b).norm() / b.norm()
         assert rel < 2e-2, (name, rel.item())
         assert (a - b).abs().max() < 0.05 * b.abs().max() + 1e-2, name
+
+
+@pytest.mark.parametrize("C", [16, 48, 256, 768])
+@pytest.mark.parametrize("xdt,ydt,hdt", [(torch.float32, torch.float32, torch.float32), (torch.float32, torch.bfloat16, torch.bfloat16),
+                                         (torch.bfloat16, torch.bfloat16, torch.bfloat16)])
+def test_fused_add_layernorm_against_torch(C, xdt, ydt, hdt):
+    """csrc/norm.hip vs the plain fp32 PyTorch composition x + s*y -> LayerNorm, forward and backward
+    (incl. the bf16-copy gradient path and the DropPath row scale)."""
+    from scenesplat_amd import functional as SF
+    g = torch.Generator().manual_seed(C)
+    n = 1037
+    x = torch.randn(n, C, generator=g).to(xdt); y = torch.randn(n, C, generator=g).to(ydt)
+    rs = (torch.rand(n, generator=g) < 0.7).float() / 0.7
+    gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    cx, ch, cc = torch.randn(n, C, generator=g), torch.randn(n, C, generator=g), torch.randn(n, C, generator=g)
+    # reference
+    xr, yr, gr, br = (t.float().clone().requires_grad_(True) for t in (x, y, gam, bet))
+    vo = xr + rs[:, None] * yr
+    ho = F.layer_norm(vo, (C,), gr, br, 1e-5)
+    (vo * cx + ho * ch + vo.to(torch.bfloat16).float() * cc).sum().backward()   # bf16 copy: straight-through for the gradient
+    xg, yg, gg, bg = (t.cuda().requires_grad_(True) for t in (x, y, gam, bet))
+    xo, h, xc = SF.add_layer_norm(xg, yg, rs.cuda(), gg, bg, 1e-5, True, hdt)
+    assert xo.dtype == torch.float32 and h.dtype == hdt and xc.dtype == torch.bfloat16
+    (xo * cx.cuda() + h.float() * ch.cuda() + xc.float() * cc.cuda()).sum().backward()
+    tol = 1e-5 if hdt == torch.float32 else 2e-2
+    assert torch.allclose(xo.cpu(), vo.detach(), atol=1e-6)
+    assert torch.allclose(h.float().cpu(), ho.detach(), atol=tol, rtol=tol)
+    assert torch.allclose(xc.float().cpu(), vo.detach(), atol=1e-2, rtol=8e-3)     # bf16 rounding of the fused sum (fma contraction may flip an ulp)
+    gtol = 2e-5 if ydt == torch.float32 else 3e-2
+    assert torch.allclose(xg.grad.float().cpu(), xr.grad, atol=gtol if xdt == torch.float32 else 3e-2, rtol=1e-2)
+    assert torch.allclose(yg.grad.float().cpu(), yr.grad, atol=gtol, rtol=1e-2)
+    ptol = 1e-3 if hdt == torch.float32 else 8e-3      # bf16 h => the incoming gradient is rounded to bf16 by autograd
+    assert (gg.grad.cpu() - gr.grad).norm() <= ptol * gr.grad.norm() + 1e-4
+    assert (bg.grad.cpu() - br.grad).norm() <= ptol * br.grad.norm() + 1e-4
+    # plain LN (no add), bf16 in / bf16 out as used for cpe.2
+    t = torch.randn(n, C, generator=g).to(ydt)
+    tr, gr, br = t.float().clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    (F.layer_norm(tr, (C,), gr, br, 1e-5) * ch).sum().backward()
+    tg, gg, bg = t.cuda().requires_grad_(True), gam.cuda().requires_grad_(True), bet.cuda().requires_grad_(True)
+    o = SF.layer_norm(tg, gg, bg, 1e-5)
+    assert o.dtype == ydt
+    (o.float() * ch.cuda()).sum().backward()
+    assert torch.allclose(tg.grad.float().cpu(), tr.grad, atol=gtol, rtol=2e-2)
+    assert (gg.grad.cpu() - gr.grad).norm() <= (2e-3 if ydt == torch.float32 else 1e-2) * gr.grad.norm() + 1e-4
