@@ -91,9 +91,13 @@ int ss_subm_rulebook(const int32_t* grid_coord, const int32_t* batch, int64_t n,
  * transposed weight (cin,taps,cout). */
 int ss_subm_conv_fwd(const void* in, const void* weight, const float* bias, const int32_t* nbr, const int32_t* rowperm,
                      void* out, int64_t n, int cin, int cout, int taps, int out_dtype, ss_stream_t stream);
+/* per tap, the 64-site blocks (in rowperm order) that hold at least one pair: blk_count (taps), blk_list (taps, ceil(n/64)) */
+int ss_subm_block_lists(const int32_t* nbr, const int32_t* rowperm, int64_t n, int taps, int32_t* blk_count,
+                        int32_t* blk_list, ss_stream_t stream);
 /* dweight (cout,taps,cin) f32, ACCUMULATED into (caller zeroes it); cin % 8 == 0, cout % 8 == 0 */
-int ss_subm_conv_wgrad(const void* in, const void* dout, const int32_t* nbr, const int32_t* rowperm, float* dweight,
-                       int64_t n, int cin, int cout, int taps, ss_stream_t stream);
+int ss_subm_conv_wgrad(const void* in, const void* dout, const int32_t* nbr, const int32_t* rowperm,
+                       const int32_t* blk_count, const int32_t* blk_list, float* dweight, int64_t n, int cin, int cout,
+                       int taps, ss_stream_t stream);
 
 /* ---- fused residual add (+ DropPath row scale) + LayerNorm (ptv3:318-338 seams) ------------------------
  * v = x + rowscale*y; xout = v (f32/bf16) [+ bf16 copy]; h = LN(v)*gamma+beta.  NULL = absent.  C % 4 == 0, C <= 1024. */

@@ -142,57 +142,103 @@ k_subm_gemm(const unsigned short* __restrict__ in, const unsigned short* __restr
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = MFMA16(af[mi], bf[ni], acc[mi][ni]);
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = MFMA16(bf[ni], af[mi], acc[mi][ni]);   // C^T: rows = channels
       }
       if (it + 1 < iters) stage_write(b ^ 1);
       __syncthreads();
     }
   }
-  // epilogue: acc[mi][ni][r] -> row 64wm + 16mi + 4g + r, col 64wn + 16ni + lq
+  // epilogue: acc[mi][ni] holds C^T: element r = channel n0 + 64wn + 16ni + 4g + r of site 64wm + 16mi + lq
+  // -> one 8-byte (bf16) / 16-byte (f32) store per tile instead of four 2-byte ones
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni) {
-    int col = n0 + 64 * wn + 16 * ni + lq;
-    if (col < Cout) {
-      float bv = bias ? bias[col] : 0.f;
+  for (int mi = 0; mi < 4; ++mi) {
+    const int row = rowid_s[64 * wm + 16 * mi + lq];
+    if (row < 0) continue;
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int row = rowid_s[64 * wm + 16 * mi + 4 * g + r];
-          if (row >= 0) ElemIO<OutT>::store(out + (int64_t)row * Cout + col, acc[mi][ni][r] + bv);
+    for (int ni = 0; ni < 4; ++ni) {
+      const int col = n0 + 64 * wn + 16 * ni + 4 * g;
+      if (col + 3 < Cout && (Cout & 3) == 0) {
+        float4 v = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
+        if (bias) { float4 bv = *reinterpret_cast<const float4*>(bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+        OutT* op = out + (int64_t)row * Cout + col;
+        if (sizeof(OutT) == 2) {
+          uint2 u; u.x = pack_bf16x2(v.x, v.y); u.y = pack_bf16x2(v.z, v.w);
+          *reinterpret_cast<uint2*>(op) = u;
+        } else {
+          *reinterpret_cast<float4*>(op) = v;
         }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col + r < Cout) ElemIO<OutT>::store(out + (int64_t)row * Cout + col + r, acc[mi][ni][r] + (bias ? bias[col + r] : 0.f));
+      }
     }
   }
 }
 
-// dW[co][t][ci] += sum over the sites of this split
+// active 64-site blocks per tap (in rowperm order): blk_list[t][0 .. blk_count[t])
+__global__ void k_subm_block_lists(const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowperm, int n, int nblocks,
+                                   int32_t* __restrict__ blk_count, int32_t* __restrict__ blk_list) {
+  __shared__ int flags_s[4];
+  __shared__ int cnt_s;
+  const int t = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) cnt_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 4) {
+    int blk = base + wave, k = blk * 64 + lane;
+    int j = -1;
+    if (blk < nblocks && k < n) j = nbr[(int64_t)t * n + (rowperm ? rowperm[k] : k)];
+    unsigned long long m = __ballot(j >= 0);
+    if (lane == 0) flags_s[wave] = m != 0ULL;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int c = cnt_s;
+      for (int w = 0; w < 4; ++w) if (flags_s[w]) blk_list[(int64_t)t * nblocks + c++] = base + w;
+      cnt_s = c;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) blk_count[t] = cnt_s;
+}
+
+extern "C" int ss_subm_block_lists(const int32_t* nbr, const int32_t* rowperm, int64_t n, int taps, int32_t* blk_count,
+                                   int32_t* blk_list, hipStream_t stream) {
+  if (n <= 0 || taps <= 0 || n >= (1LL << 31)) return SS_ERR_ARG;
+  SS_LAUNCH(k_subm_block_lists, dim3(taps), dim3(256), 0, stream, nbr, rowperm, (int)n, ss_div_up(n, 64), blk_count, blk_list);
+  return SS_OK;
+}
+
+// dW[co][t][ci] += sum over this workgroup's share of the tap's ACTIVE 64-site blocks
 __global__ void __launch_bounds__(CV_THREADS, 2)
 k_subm_wgrad(const unsigned short* __restrict__ in, const unsigned short* __restrict__ dout,
-             const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowperm, float* __restrict__ dW, int n, int Cin,
-             int Cout, int taps, int ntiles_n, int sites_per_split) {
+             const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowperm, const int32_t* __restrict__ blk_count,
+             const int32_t* __restrict__ blk_list, float* __restrict__ dW, int n, int Cin, int Cout, int taps, int ntiles_n,
+             int nblocks_total) {
   constexpr int IMG = 64 * 256;   // 64 sites x 128 cols bf16 = 16 KB
   __shared__ __attribute__((aligned(16))) char smem[4 * IMG];   // A0 B0 A1 B1
   __shared__ int32_t isite_s[2][64], jsite_s[2][64];
-  __shared__ int any_s[2];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, g = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = (blockIdx.x / ntiles_n) * 128, n0 = (blockIdx.x % ntiles_n) * 128;
   const int tap = blockIdx.y;
-  const int kbeg = blockIdx.z * sites_per_split, kend = min(n, kbeg + sites_per_split);
+  const int cnt = blk_count[tap];
+  const int per = (cnt + gridDim.z - 1) / gridDim.z;
+  const int beg = blockIdx.z * per, end = min(cnt, beg + per);
+  const int nblk = end - beg;
+  if (nblk <= 0) return;
+  const int32_t* list = blk_list + (int64_t)tap * nblocks_total + beg;
   f32x4_t acc[4][4];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   uint4 sa[4], sb[4];
-  auto index_load = [&](int b, int k0) {      // wave 0: site ids of the block + "any neighbour" flag
+  auto index_load = [&](int b, int blk) {      // wave 0: site ids of the block
     if (tid < 64) {
-      int k = k0 + tid;
-      int i = k < kend ? (rowperm ? rowperm[k] : k) : -1;
-      int j = i >= 0 ? nbr[(int64_t)tap * n + i] : -1;
-      isite_s[b][tid] = i; jsite_s[b][tid] = j;
-      unsigned long long m = __ballot(j >= 0);
-      if (tid == 0) any_s[b] = m != 0ULL;
+      int k = list[blk] * 64 + tid;
+      int i = k < n ? (rowperm ? rowperm[k] : k) : -1;
+      isite_s[b][tid] = i;
+      jsite_s[b][tid] = i >= 0 ? nbr[(int64_t)tap * n + i] : -1;
     }
   };
   auto stage_load = [&](int b) {
@@ -220,19 +266,16 @@ k_subm_wgrad(const unsigned short* __restrict__ in, const unsigned short* __rest
       *reinterpret_cast<uint4*>(B + cv_tr_off(r, ch)) = sb[i];
     }
   };
-  const int nblk = (kend - kbeg + 63) / 64;
-  if (nblk <= 0) return;
-  index_load(0, kbeg);
+  index_load(0, 0);
   __syncthreads();
-  if (any_s[0]) { stage_load(0); stage_write(0); }
-  if (nblk > 1) index_load(1, kbeg + 64);
+  stage_load(0); stage_write(0);
+  if (nblk > 1) index_load(1, 1);
   __syncthreads();
   for (int blk = 0; blk < nblk; ++blk) {
     const int b = blk & 1;
     const bool have_next = blk + 1 < nblk;
-    const bool next_any = have_next && any_s[b ^ 1];
-    if (next_any) stage_load(b ^ 1);
-    if (any_s[b]) {
+    if (have_next) stage_load(b ^ 1);
+    {
       const char* A = smem + b * 2 * IMG; const char* B = A + IMG;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -255,8 +298,8 @@ k_subm_wgrad(const unsigned short* __restrict__ in, const unsigned short* __rest
       }
     }
     __syncthreads();                    // all reads of buffer b and of index slot b are done
-    if (next_any) stage_write(b ^ 1);
-    if (blk + 2 < nblk) index_load(b, kbeg + (blk + 2) * 64);
+    if (have_next) stage_write(b ^ 1);
+    if (blk + 2 < nblk) index_load(b, blk + 2);
     __syncthreads();
   }
 #pragma unroll
@@ -290,18 +333,19 @@ extern "C" int ss_subm_conv_fwd(const void* in, const void* weight, const float*
 }
 
 extern "C" int ss_subm_conv_wgrad(const void* in, const void* dout, const int32_t* nbr, const int32_t* rowperm,
-                                  float* dweight, int64_t n, int cin, int cout, int taps, hipStream_t stream) {
+                                  const int32_t* blk_count, const int32_t* blk_list, float* dweight, int64_t n, int cin,
+                                  int cout, int taps, hipStream_t stream) {
   if (n < 0 || cin <= 0 || cout <= 0 || taps <= 0 || (cin & 7) || (cout & 7) || n >= (1LL << 31)) return SS_ERR_ARG;
   if (n == 0) return SS_OK;
   const int tm = ss_div_up(cout, 128), tn = ss_div_up(cin, 128);
-  int splits = 2048 / (tm * tn * taps);
-  int max_splits = ss_div_up(n, 512);
-  if (splits > max_splits) splits = max_splits;
+  const int nblocks = ss_div_up(n, 64);
+  // taps are very unevenly populated on surfaces (about a third carry almost all pairs): size the K split for the
+  // busy ones so that ~2k workgroups of useful work exist
+  int splits = 6144 / (tm * tn * taps);
+  if (splits > nblocks / 8) splits = nblocks / 8;
   if (splits < 1) splits = 1;
-  int sps = ss_div_up(ss_div_up(n, splits), 64) * 64;
-  splits = ss_div_up(n, sps);
   dim3 g(tm * tn, taps, splits), b(CV_THREADS);
-  SS_LAUNCH(k_subm_wgrad, g, b, 0, stream, (const unsigned short*)in, (const unsigned short*)dout, nbr, rowperm, dweight,
-            (int)n, cin, cout, taps, tn, sps);
+  SS_LAUNCH(k_subm_wgrad, g, b, 0, stream, (const unsigned short*)in, (const unsigned short*)dout, nbr, rowperm, blk_count,
+            blk_list, dweight, (int)n, cin, cout, taps, tn, nblocks);
   return SS_OK;
 }

@@ -131,7 +131,7 @@ class _SubMConv3dFused(torch.autograd.Function):
     (same kernel, tap-mirrored transposed weights) and wgrad.  Needs unique voxels."""
 
     @staticmethod
-    def forward(ctx, feat, weight, bias, nbr, rowperm):
+    def forward(ctx, feat, weight, bias, nbr, rowperm, blocks_fn):
         taps, n = nbr.shape
         cout, cin = weight.shape[0], weight.shape[-1]
         pad = (-cin) % 8
@@ -143,6 +143,7 @@ class _SubMConv3dFused(torch.autograd.Function):
         out = nv.subm_conv_fwd(x, w, None if bias is None else bias.float().contiguous(), nbr, rowperm)
         ctx.save_for_backward(x, w, nbr, rowperm)
         ctx.meta = (feat.dtype, weight.dtype, weight.shape, cin, bias is not None)
+        ctx.blocks_fn = blocks_fn
         return out
 
     @staticmethod
@@ -155,17 +156,18 @@ class _SubMConv3dFused(torch.autograd.Function):
             wt = w.flip(1).permute(2, 1, 0).contiguous()          # [ci][t'][co] = w[co][T-1-t'][ci]
             dx = nv.subm_conv_fwd(g, wt, None, nbr, rowperm)[:, :cin].to(in_dtype)
         if ctx.needs_input_grad[1]:
-            dw = nv.subm_conv_wgrad(x, g, nbr, rowperm)[:, :, :cin].reshape(w_shape).to(w_dtype)
+            blocks = ctx.blocks_fn() if ctx.blocks_fn is not None else nv.subm_block_lists(nbr, rowperm)
+            dw = nv.subm_conv_wgrad(x, g, nbr, rowperm, blocks)[:, :, :cin].reshape(w_shape).to(w_dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = g.float().sum(0).to(w_dtype)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def subm_conv3d(feat, weight, bias, nbr, has_dup=False, compute_dtype=torch.float32, rowperm=None):
+def subm_conv3d(feat, weight, bias, nbr, has_dup=False, compute_dtype=torch.float32, rowperm=None, blocks_fn=None):
     """weight (Cout, k, k, k, Cin) as in the reference checkpoints; nbr (k^3, n) tap-major.
     bf16 compute on unique voxels -> fused MFMA kernels; otherwise per-tap gather + GEMM."""
     if compute_dtype == torch.bfloat16 and not has_dup and weight.shape[0] % 8 == 0:
-        return _SubMConv3dFused.apply(feat, weight, bias, nbr, rowperm)
+        return _SubMConv3dFused.apply(feat, weight, bias, nbr, rowperm, blocks_fn)
     return _SubMConv3d.apply(feat, weight, bias, nbr, has_dup, compute_dtype)
 
 

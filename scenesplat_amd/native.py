@@ -170,8 +170,21 @@ def subm_conv_fwd(x, w, bias, nbr, rowperm, out_dtype=torch.bfloat16):
     return out
 
 
-def subm_conv_wgrad(x, dout, nbr, rowperm):
-    """-> dW (cout,taps,cin) f32 = sum_i dout[i] (x) x[nbr[t][i]]."""
+def subm_block_lists(nbr, rowperm):
+    """Per tap the compacted list of 64-site blocks with at least one pair: (count (taps), list (taps, nblocks))."""
+    taps, n = nbr.shape
+    _req(nbr, torch.int32, "nbr")
+    if rowperm is not None:
+        _req(rowperm, torch.int32, "rowperm", (n,))
+    nb = (n + 63) // 64
+    cnt = torch.empty(taps, dtype=torch.int32, device=nbr.device)
+    lst = torch.empty((taps, nb), dtype=torch.int32, device=nbr.device)
+    check(lib().ss_subm_block_lists(_p(nbr), _p(rowperm), n, taps, _p(cnt), _p(lst), _stream()), "ss_subm_block_lists")
+    return cnt, lst
+
+
+def subm_conv_wgrad(x, dout, nbr, rowperm, blocks):
+    """-> dW (cout,taps,cin) f32 = sum_i dout[i] (x) x[nbr[t][i]].  blocks = subm_block_lists(nbr, rowperm)."""
     n, cin = x.shape
     cout = dout.shape[1]
     taps = nbr.shape[0]
@@ -181,8 +194,10 @@ def subm_conv_wgrad(x, dout, nbr, rowperm):
     if rowperm is not None:
         _req(rowperm, torch.int32, "rowperm", (n,))
     dw = torch.zeros((cout, taps, cin), dtype=torch.float32, device=x.device)
-    check(lib().ss_subm_conv_wgrad(_p(x), _p(dout), _p(nbr), _p(rowperm), _p(dw), n, cin, cout, taps, _stream()),
-          "ss_subm_conv_wgrad")
+    cnt, lst = blocks
+    _req(cnt, torch.int32, "blk_count", (taps,)); _req(lst, torch.int32, "blk_list", (taps, (n + 63) // 64))
+    check(lib().ss_subm_conv_wgrad(_p(x), _p(dout), _p(nbr), _p(rowperm), _p(cnt), _p(lst), _p(dw), n, cin, cout, taps,
+                                   _stream()), "ss_subm_conv_wgrad")
     return dw
 
 

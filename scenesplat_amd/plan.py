@@ -95,6 +95,15 @@ class Level:
                 return self.order[r]
         return self.order[0]
 
+    def conv_blocks(self, ksize):
+        """Per-tap lists of the 64-site blocks (in conv_rowperm order) that hold a pair: wgrad work list."""
+        key = ("blocks", ksize)
+        b = self._nbr.get(key)
+        if b is None:
+            b = nv.subm_block_lists(self.neighbors(ksize), self.conv_rowperm())
+            self._nbr[key] = b
+        return b
+
     def neighbors(self, ksize):
         """(k^3, n) int32 tap-major rulebook, shared by every conv of this level (indice_key)."""
         nb = self._nbr.get(ksize)

@@ -65,7 +65,8 @@ class SubMConv3d(nn.Module):
     def forward(self, feat, level):
         cd = RUNTIME["conv_dtype"] or torch.float32
         return SF.subm_conv3d(feat, self.weight, self.bias, level.neighbors(self.kernel_size),
-                              level.has_duplicates, cd, level.conv_rowperm())
+                              level.has_duplicates, cd, level.conv_rowperm(),
+                              lambda: level.conv_blocks(self.kernel_size))
 
 
 class SerializedAttention(PointModule):

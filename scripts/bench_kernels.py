@@ -42,7 +42,8 @@ def main():
             gout = torch.randn(n, C, device="cuda", generator=g).to(torch.bfloat16)
             act = (nbr >= 0).float().sum().item() / n
             tf = ev(lambda: nv.subm_conv_fwd(x, w, None, nbr, perm), 5, 2)
-            tw = ev(lambda: nv.subm_conv_wgrad(x, gout, nbr, perm), 5, 2)
+            blocks = lv.conv_blocks(3)
+            tw = ev(lambda: nv.subm_conv_wgrad(x, gout, nbr, perm, blocks), 5, 2)
             fl = 2.0 * n * act * C * C
             print(f"conv L{li} n={n} C={C} taps/site={act:.2f}: fwd {tf:.3f} ms ({fl/tf/1e9:.0f} TF/s)  wgrad {tw:.3f} ms ({fl/tw/1e9:.0f} TF/s)", flush=True)
 
