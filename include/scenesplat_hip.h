@@ -111,6 +111,19 @@ int ss_add_layernorm_bwd(const void* g_xout, int g_xout_dtype, const void* g_xco
                          const float* gamma, const float* rowscale, void* g_x, int g_x_dtype, void* g_y, int g_y_dtype,
                          float* dgamma_part, float* dbeta_part, int64_t n, int channels, int nblocks, ss_stream_t stream);
 
+/* ---- fused BatchNorm1d (+ exact GELU when act = 1) over (n, C) rows; mean/rstd per channel from the caller --------
+ * ss_col_stats: per-block partial column sums of (x - shift) and (x - shift)^2 -> psum/psq (nblocks, C) */
+int ss_col_stats(const void* x, int x_dtype, const float* shift, float* psum, float* psq, int64_t n, int channels,
+                 int nblocks, ss_stream_t stream);
+int ss_bn_act_fwd(const void* x, int x_dtype, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                  int act, void* y, int y_dtype, int64_t n, int channels, ss_stream_t stream);
+int ss_bn_act_bwd_reduce(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
+                         const float* gamma, const float* beta, int act, float* pdz, float* pdzx, int64_t n, int channels,
+                         int nblocks, ss_stream_t stream);
+int ss_bn_act_bwd_apply(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, int act, const float* c1, const float* c2, void* dx,
+                        int dx_dtype, int64_t n, int channels, ss_stream_t stream);
+
 /* ---- row movement ------------------------------------------------------------------------ */
 int ss_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_dst, int64_t row_bytes, ss_stream_t stream);
 int ss_scatter_rows(const void* src, const int32_t* idx, void* dst, int64_t n_src, int64_t row_bytes, ss_stream_t stream);

@@ -44,6 +44,10 @@ PROTOTYPES = {
     "ss_add_layernorm_bwd_blocks": (c_i, [c_i64]),
     "ss_add_layernorm_bwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p,
                                    c_i64, c_i, c_i, c_p]),
+    "ss_col_stats": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i64, c_i, c_i, c_p]),
+    "ss_bn_act_fwd": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i64, c_i, c_p]),
+    "ss_bn_act_bwd_reduce": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_i, c_p]),
+    "ss_bn_act_bwd_apply": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i64, c_i, c_p]),
     "ss_gather_rows": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_p]),
     "ss_scatter_rows": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_p]),
     "ss_gather_add_rows": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p]),

@@ -200,3 +200,209 @@ extern "C" int ss_add_layernorm_bwd(const void* g_xout, int g_xout_dtype, const 
 #undef SS_LN_BWD
   return SS_OK;
 }
+
+// =====================================================================================
+// Fused BatchNorm1d (+ exact erf GELU) over (n, C) rows: pooling / unpooling / stem norms
+// (ptv3:581 eps 1e-3; ptv3:439-442, 461-467, 508-511).  Column statistics use the same
+// wave-per-row, lane-per-4-columns mapping as the LayerNorm backward: per-lane register partials
+// over a grid-stride row loop, LDS reduction across the block's waves, one partial row per block.
+// =====================================================================================
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float z) {
+  return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+}
+
+template <int IT>
+__device__ __forceinline__ void col_partials_store(float4 (&a)[IT], float4 (&b)[IT], float* pa, float* pb, int C) {
+  __shared__ float red[2][LN_THREADS / 64][IT * 4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    red[0][wave][i * 4 + 0][lane] = a[i].x; red[0][wave][i * 4 + 1][lane] = a[i].y;
+    red[0][wave][i * 4 + 2][lane] = a[i].z; red[0][wave][i * 4 + 3][lane] = a[i].w;
+    red[1][wave][i * 4 + 0][lane] = b[i].x; red[1][wave][i * 4 + 1][lane] = b[i].y;
+    red[1][wave][i * 4 + 2][lane] = b[i].z; red[1][wave][i * 4 + 3][lane] = b[i].w;
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int j = i * 256 + lane * 4 + e;
+        if (j < C) {
+          float s0 = 0.f, s1 = 0.f;
+          for (int w = 0; w < LN_THREADS / 64; ++w) { s0 += red[0][w][i * 4 + e][lane]; s1 += red[1][w][i * 4 + e][lane]; }
+          pa[(int64_t)blockIdx.x * C + j] = s0;
+          pb[(int64_t)blockIdx.x * C + j] = s1;
+        }
+      }
+  }
+}
+
+// partial column sums of x and x^2 (shifted by `shift[c]` for conditioning; shift may be NULL)
+template <int IT>
+__global__ void __launch_bounds__(LN_THREADS)
+k_col_stats(const void* __restrict__ x, int x_dt, const float* __restrict__ shift, float* __restrict__ psum,
+            float* __restrict__ psq, int64_t n, int C) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int waves_total = gridDim.x * (LN_THREADS / 64);
+  float4 s[IT], q[IT], sh[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    s[i] = make_float4(0.f, 0.f, 0.f, 0.f); q[i] = s[i]; sh[i] = s[i];
+    int j = i * 256 + lane * 4;
+    if (shift && j < C) sh[i] = *reinterpret_cast<const float4*>(shift + j);
+  }
+  for (int64_t row = (int64_t)blockIdx.x * (LN_THREADS / 64) + wave; row < n; row += waves_total) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int j = i * 256 + lane * 4;
+      if (j < C) {
+        float4 a = ln_ld4(x, x_dt, row * C + j);
+        a.x -= sh[i].x; a.y -= sh[i].y; a.z -= sh[i].z; a.w -= sh[i].w;
+        s[i].x += a.x; s[i].y += a.y; s[i].z += a.z; s[i].w += a.w;
+        q[i].x += a.x * a.x; q[i].y += a.y * a.y; q[i].z += a.z * a.z; q[i].w += a.w * a.w;
+      }
+    }
+  }
+  col_partials_store<IT>(s, q, psum, psq, C);
+}
+
+// y = act((x - mean) * rstd * gamma + beta)
+template <int IT>
+__global__ void __launch_bounds__(LN_THREADS)
+k_bn_act_fwd(const void* __restrict__ x, int x_dt, const float* __restrict__ mean, const float* __restrict__ rstd,
+             const float* __restrict__ gamma, const float* __restrict__ beta, int act, void* __restrict__ y, int y_dt,
+             int64_t n, int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6);
+  if (row >= n) return;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int j = i * 256 + lane * 4;
+    if (j < C) {
+      float4 a = ln_ld4(x, x_dt, row * C + j);
+      float4 m = *reinterpret_cast<const float4*>(mean + j), r = *reinterpret_cast<const float4*>(rstd + j);
+      float4 g = *reinterpret_cast<const float4*>(gamma + j), b = *reinterpret_cast<const float4*>(beta + j);
+      float4 z = make_float4((a.x - m.x) * r.x * g.x + b.x, (a.y - m.y) * r.y * g.y + b.y, (a.z - m.z) * r.z * g.z + b.z,
+                             (a.w - m.w) * r.w * g.w + b.w);
+      if (act) z = make_float4(gelu_f(z.x), gelu_f(z.y), gelu_f(z.z), gelu_f(z.w));
+      ln_st4(y, y_dt, row * C + j, z);
+    }
+  }
+}
+
+// backward pass 1: dz = dy * act'(z); partial column sums of dz and dz * xhat
+template <int IT>
+__global__ void __launch_bounds__(LN_THREADS)
+k_bn_act_bwd_reduce(const void* __restrict__ dy, int dy_dt, const void* __restrict__ x, int x_dt,
+                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                    const float* __restrict__ beta, int act, float* __restrict__ pdz, float* __restrict__ pdzx, int64_t n,
+                    int C) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int waves_total = gridDim.x * (LN_THREADS / 64);
+  float4 s[IT], q[IT], m[IT], r[IT], g[IT], b[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    s[i] = make_float4(0.f, 0.f, 0.f, 0.f); q[i] = s[i]; m[i] = s[i]; r[i] = s[i]; g[i] = s[i]; b[i] = s[i];
+    int j = i * 256 + lane * 4;
+    if (j < C) {
+      m[i] = *reinterpret_cast<const float4*>(mean + j); r[i] = *reinterpret_cast<const float4*>(rstd + j);
+      g[i] = *reinterpret_cast<const float4*>(gamma + j); b[i] = *reinterpret_cast<const float4*>(beta + j);
+    }
+  }
+  for (int64_t row = (int64_t)blockIdx.x * (LN_THREADS / 64) + wave; row < n; row += waves_total) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int j = i * 256 + lane * 4;
+      if (j < C) {
+        float4 a = ln_ld4(x, x_dt, row * C + j), d = ln_ld4(dy, dy_dt, row * C + j);
+        float4 xh = make_float4((a.x - m[i].x) * r[i].x, (a.y - m[i].y) * r[i].y, (a.z - m[i].z) * r[i].z, (a.w - m[i].w) * r[i].w);
+        if (act) {
+          d.x *= dgelu_f(xh.x * g[i].x + b[i].x); d.y *= dgelu_f(xh.y * g[i].y + b[i].y);
+          d.z *= dgelu_f(xh.z * g[i].z + b[i].z); d.w *= dgelu_f(xh.w * g[i].w + b[i].w);
+        }
+        s[i].x += d.x; s[i].y += d.y; s[i].z += d.z; s[i].w += d.w;
+        q[i].x += d.x * xh.x; q[i].y += d.y * xh.y; q[i].z += d.z * xh.z; q[i].w += d.w * xh.w;
+      }
+    }
+  }
+  col_partials_store<IT>(s, q, pdz, pdzx, C);
+}
+
+// backward pass 2: dx = gamma * rstd * (dz - c1 - xhat * c2); training: c1 = sum_dz / n, c2 = sum_dzx / n; eval: 0
+template <int IT>
+__global__ void __launch_bounds__(LN_THREADS)
+k_bn_act_bwd_apply(const void* __restrict__ dy, int dy_dt, const void* __restrict__ x, int x_dt,
+                   const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                   const float* __restrict__ beta, int act, const float* __restrict__ c1, const float* __restrict__ c2,
+                   void* __restrict__ dx, int dx_dt, int64_t n, int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6);
+  if (row >= n) return;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int j = i * 256 + lane * 4;
+    if (j < C) {
+      float4 a = ln_ld4(x, x_dt, row * C + j), d = ln_ld4(dy, dy_dt, row * C + j);
+      float4 m = *reinterpret_cast<const float4*>(mean + j), r = *reinterpret_cast<const float4*>(rstd + j);
+      float4 g = *reinterpret_cast<const float4*>(gamma + j), b = *reinterpret_cast<const float4*>(beta + j);
+      float4 k1 = c1 ? *reinterpret_cast<const float4*>(c1 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 k2 = c2 ? *reinterpret_cast<const float4*>(c2 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 xh = make_float4((a.x - m.x) * r.x, (a.y - m.y) * r.y, (a.z - m.z) * r.z, (a.w - m.w) * r.w);
+      if (act) {
+        d.x *= dgelu_f(xh.x * g.x + b.x); d.y *= dgelu_f(xh.y * g.y + b.y);
+        d.z *= dgelu_f(xh.z * g.z + b.z); d.w *= dgelu_f(xh.w * g.w + b.w);
+      }
+      float4 o = make_float4(g.x * r.x * (d.x - k1.x - xh.x * k2.x), g.y * r.y * (d.y - k1.y - xh.y * k2.y),
+                             g.z * r.z * (d.z - k1.z - xh.z * k2.z), g.w * r.w * (d.w - k1.w - xh.w * k2.w));
+      ln_st4(dx, dx_dt, row * C + j, o);
+    }
+  }
+}
+
+#define SS_IT_SWITCH(MACRO) switch (it) { case 1: MACRO(1); break; case 2: MACRO(2); break; case 3: MACRO(3); break; default: MACRO(4); break; }
+
+extern "C" int ss_col_stats(const void* x, int x_dtype, const float* shift, float* psum, float* psq, int64_t n, int channels,
+                            int nblocks, hipStream_t stream) {
+  if (n < 0 || channels <= 0 || (channels & 3) || channels > LN_MAXIT * 256 || nblocks < 1) return SS_ERR_ARG;
+  const int it = (channels + 255) / 256;
+#define SS_CS(ITN) SS_LAUNCH(k_col_stats<ITN>, dim3(nblocks), dim3(LN_THREADS), 0, stream, x, x_dtype, shift, psum, psq, n, channels)
+  SS_IT_SWITCH(SS_CS)
+#undef SS_CS
+  return SS_OK;
+}
+extern "C" int ss_bn_act_fwd(const void* x, int x_dtype, const float* mean, const float* rstd, const float* gamma,
+                             const float* beta, int act, void* y, int y_dtype, int64_t n, int channels, hipStream_t stream) {
+  if (n < 0 || channels <= 0 || (channels & 3) || channels > LN_MAXIT * 256) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  const int it = (channels + 255) / 256;
+  dim3 g(ss_div_up(n, LN_THREADS / 64)), b(LN_THREADS);
+#define SS_BF(ITN) SS_LAUNCH(k_bn_act_fwd<ITN>, g, b, 0, stream, x, x_dtype, mean, rstd, gamma, beta, act, y, y_dtype, n, channels)
+  SS_IT_SWITCH(SS_BF)
+#undef SS_BF
+  return SS_OK;
+}
+extern "C" int ss_bn_act_bwd_reduce(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean,
+                                    const float* rstd, const float* gamma, const float* beta, int act, float* pdz, float* pdzx,
+                                    int64_t n, int channels, int nblocks, hipStream_t stream) {
+  if (n < 0 || channels <= 0 || (channels & 3) || channels > LN_MAXIT * 256 || nblocks < 1) return SS_ERR_ARG;
+  const int it = (channels + 255) / 256;
+#define SS_BR(ITN) SS_LAUNCH(k_bn_act_bwd_reduce<ITN>, dim3(nblocks), dim3(LN_THREADS), 0, stream, dy, dy_dtype, x, x_dtype, mean, rstd, gamma, beta, act, pdz, pdzx, n, channels)
+  SS_IT_SWITCH(SS_BR)
+#undef SS_BR
+  return SS_OK;
+}
+extern "C" int ss_bn_act_bwd_apply(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean,
+                                   const float* rstd, const float* gamma, const float* beta, int act, const float* c1,
+                                   const float* c2, void* dx, int dx_dtype, int64_t n, int channels, hipStream_t stream) {
+  if (n < 0 || channels <= 0 || (channels & 3) || channels > LN_MAXIT * 256) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  const int it = (channels + 255) / 256;
+  dim3 g(ss_div_up(n, LN_THREADS / 64)), b(LN_THREADS);
+#define SS_BA(ITN) SS_LAUNCH(k_bn_act_bwd_apply<ITN>, g, b, 0, stream, dy, dy_dtype, x, x_dtype, mean, rstd, gamma, beta, act, c1, c2, dx, dx_dtype, n, channels)
+  SS_IT_SWITCH(SS_BA)
+#undef SS_BA
+  return SS_OK;
+}

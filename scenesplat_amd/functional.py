@@ -159,7 +159,7 @@ class _SubMConv3dFused(torch.autograd.Function):
             blocks = ctx.blocks_fn() if ctx.blocks_fn is not None else nv.subm_block_lists(nbr, rowperm)
             dw = nv.subm_conv_wgrad(x, g, nbr, rowperm, blocks)[:, :, :cin].reshape(w_shape).to(w_dtype)
         if has_bias and ctx.needs_input_grad[2]:
-            db = g.float().sum(0).to(w_dtype)
+            db = g.sum(0, dtype=torch.float32).to(w_dtype)
         return dx, dw, db, None, None, None
 
 
@@ -225,3 +225,45 @@ class _AddLayerNorm(torch.autograd.Function):
 def add_layer_norm(x, y, rowscale=None, gamma=None, beta=None, eps=1e-5, want_copy=False, h_dtype=torch.float32):
     """Fused residual seam: returns (xout fp32, h or None, bf16 copy of xout or None)."""
     return _AddLayerNorm.apply(x, y, rowscale, gamma, beta, eps, want_copy, h_dtype)
+
+
+class _BatchNormAct(torch.autograd.Function):
+    """BatchNorm1d (training: batch statistics + running-stat update; eval: running statistics) fused with
+    an optional exact GELU, 2 passes forward / 2 passes backward (csrc/norm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act):
+        x = x.contiguous()
+        n = x.shape[0]
+        if training:
+            shift = running_mean.float().contiguous()              # conditioning of the one-pass variance
+            s, q = nv.col_stats(x, shift)
+            d = s / n
+            mean = shift + d
+            var = (q / n - d * d).clamp_(min=0.0)
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+                running_var.mul_(1 - momentum).add_((var * (n / max(n - 1, 1))).to(running_var.dtype), alpha=momentum)
+        else:
+            mean, var = running_mean.float(), running_var.float()
+        rstd = torch.rsqrt(var + eps).contiguous()
+        mean = mean.contiguous()
+        g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
+        y = nv.bn_act_fwd(x, mean, rstd, g32, b32, act, x.dtype)
+        ctx.save_for_backward(x, mean, rstd, g32, b32)
+        ctx.meta = (training, act, gamma.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, g32, b32 = ctx.saved_tensors
+        training, act, pdt = ctx.meta
+        dx, dg, db = nv.bn_act_bwd(dy.contiguous(), x, mean, rstd, g32, b32, act, training)
+        return dx, dg.to(pdt), db.to(pdt), None, None, None, None, None, None
+
+
+def batch_norm_act(x, bn, act=False):
+    """x (n, C) through an nn.BatchNorm1d's parameters / buffers (updates running stats in training)."""
+    if bn.training:
+        bn.num_batches_tracked.add_(1)
+    return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, act)

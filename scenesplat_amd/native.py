@@ -250,6 +250,42 @@ def add_layernorm_bwd(g_xout, g_xcopy, g_h, v, mean, rstd, gamma, rowscale, gx_d
     return g_x, g_y, None, None
 
 
+# ---- fused batchnorm (+GELU) ----------------------------------------------------------------------
+def col_stats(x, shift=None):
+    """-> (sum, sumsq) of (x - shift) per column, fp32 (partials reduced here)."""
+    n, C = x.shape
+    _req(x, None, "x")
+    nb = lib().ss_add_layernorm_bwd_blocks(n)
+    ps = torch.empty((nb, C), dtype=torch.float32, device=x.device); pq = torch.empty_like(ps)
+    check(lib().ss_col_stats(_p(x), _dt(x), _p(shift), _p(ps), _p(pq), n, C, nb, _stream()), "ss_col_stats")
+    return ps.sum(0), pq.sum(0)
+
+
+def bn_act_fwd(x, mean, rstd, gamma, beta, act, out_dtype):
+    n, C = x.shape
+    y = torch.empty((n, C), dtype=out_dtype, device=x.device)
+    check(lib().ss_bn_act_fwd(_p(x), _dt(x), _p(mean), _p(rstd), _p(gamma), _p(beta), int(act), _p(y), _dt(y), n, C, _stream()),
+          "ss_bn_act_fwd")
+    return y
+
+
+def bn_act_bwd(dy, x, mean, rstd, gamma, beta, act, training):
+    """-> dx (x.dtype), dgamma, dbeta (fp32)"""
+    n, C = x.shape
+    _req(dy, None, "dy", (n, C))
+    nb = lib().ss_add_layernorm_bwd_blocks(n)
+    pz = torch.empty((nb, C), dtype=torch.float32, device=x.device); pzx = torch.empty_like(pz)
+    check(lib().ss_bn_act_bwd_reduce(_p(dy), _dt(dy), _p(x), _dt(x), _p(mean), _p(rstd), _p(gamma), _p(beta), int(act), _p(pz),
+                                     _p(pzx), n, C, nb, _stream()), "ss_bn_act_bwd_reduce")
+    sdz, sdzx = pz.sum(0), pzx.sum(0)
+    c1 = (sdz / n).contiguous() if training else None
+    c2 = (sdzx / n).contiguous() if training else None
+    dx = torch.empty_like(x)
+    check(lib().ss_bn_act_bwd_apply(_p(dy), _dt(dy), _p(x), _dt(x), _p(mean), _p(rstd), _p(gamma), _p(beta), int(act), _p(c1),
+                                    _p(c2), _p(dx), _dt(dx), n, C, _stream()), "ss_bn_act_bwd_apply")
+    return dx, sdzx, sdz
+
+
 # ---- rows ------------------------------------------------------------------------------------
 def gather_rows(src, idx, out=None):
     """out[i] = src[idx[i]] (zero row where idx < 0).  src (m, C)."""

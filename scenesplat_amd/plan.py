@@ -72,15 +72,24 @@ class Level:
     def counts(self):
         return [self.offsets[i + 1] - self.offsets[i] for i in range(len(self.offsets) - 1)]
 
+    def _layout(self, patch):
+        """(offsets, offsets_pad, win_start) device int32 vectors + host copies for one patch size.
+        Uploaded in one pinned, non-blocking copy per patch size (a blocking torch.tensor(..., device=)
+        upload would synchronise the stream in the middle of the forward)."""
+        lay = self._windows.get(("layout", int(patch)))
+        if lay is None:
+            off_pad, win = window_layout(self.counts, int(patch))
+            packed = torch.tensor(self.offsets + off_pad + win, dtype=torch.int32).pin_memory().to(self.device, non_blocking=True)
+            a, b = len(self.offsets), len(self.offsets) + len(off_pad)
+            lay = (packed[:a], packed[a:b], packed[b:], off_pad, win)
+            self._windows[("layout", int(patch))] = lay
+        return lay
+
     def window(self, j, patch):
         key = (self.curves[j], int(patch))
         w = self._windows.get(key)
         if w is None:
-            off_pad, win = window_layout(self.counts, int(patch))
-            dev = self.device
-            t_off = torch.tensor(self.offsets, dtype=torch.int32, device=dev)
-            t_offp = torch.tensor(off_pad, dtype=torch.int32, device=dev)
-            t_win = torch.tensor(win, dtype=torch.int32, device=dev)
+            t_off, t_offp, t_win, off_pad, win = self._layout(patch)
             gidx, sidx = nv.window_index(self.order_row(j), t_off, t_offp, patch, off_pad[-1])
             maxw = max([win[i + 1] - win[i] for i in range(len(win) - 1)] or [0])
             w = WindowIndex(gidx, sidx, t_win, len(win) - 1, maxw, self.n, off_pad[-1], off_pad)
@@ -130,6 +139,33 @@ class Level:
 class ScenePlan:
     def __init__(self, levels, order_names):
         self.levels, self.order_names = levels, order_names
+        self.ready_event = None     # set when the plan was built on a side stream
+
+    def tensors(self):
+        for lv in self.levels:
+            for t in (lv.grid_coord, lv.batch, lv.codes, lv.order, lv.inverse, lv.codes_sorted, lv.cluster, lv.idx_ptr):
+                if t is not None:
+                    yield t
+            for v in list(lv._windows.values()) + list(lv._nbr.values()):
+                for t in (v if isinstance(v, tuple) else (v,)):
+                    if isinstance(t, torch.Tensor):
+                        yield t
+                    elif isinstance(t, WindowIndex):
+                        yield t.gidx; yield t.sidx
+
+    def materialize(self, window_specs=(), kernel_sizes=()):
+        """Build the lazily cached pieces now (on the current stream): window_specs = [(level, curve index,
+        patch)], kernel_sizes = [(level, k)]."""
+        for li, j, patch in window_specs:
+            self.levels[li].window(j, patch)
+        for li, k in kernel_sizes:
+            self.levels[li].neighbors(k); self.levels[li].conv_blocks(k)
+
+    def record_stream(self, stream):
+        """The plan was allocated on another stream: keep the caching allocator from reusing its memory
+        before `stream`'s queued work is done."""
+        for t in self.tensors():
+            t.record_stream(stream)
 
 
 def _key_bits(depth, num_batches):

@@ -154,6 +154,29 @@ class Block(PointModule):
         return self.norm2(x + self.drop_path(self.mlp(x)))
 
 
+def _norm_act(x, norm, act):
+    """BatchNorm1d (+ GELU) as one fused HIP op (csrc/norm.hip); anything else falls through to the modules."""
+    if isinstance(norm, nn.BatchNorm1d) and norm.affine and norm.track_running_stats and (act is None or isinstance(act, nn.GELU)) \
+            and x.shape[1] % 4 == 0 and x.shape[1] <= 1024:
+        return SF.batch_norm_act(x, norm, act is not None)
+    if norm is not None:
+        x = norm(x)
+    return act(x) if act is not None else x
+
+
+def _seq_lin_norm_act(seq, x):
+    """nn.Sequential(Linear[, BatchNorm1d][, GELU]) with the norm/act pair fused."""
+    mods = list(seq)
+    x = mods[0](x)
+    norm = mods[1] if len(mods) > 1 and isinstance(mods[1], nn.BatchNorm1d) else None
+    act = mods[-1] if len(mods) > 1 and isinstance(mods[-1], nn.GELU) else None
+    if norm is None and act is None:
+        for mod in mods[1:]:
+            x = mod(x)
+        return x
+    return _norm_act(x, norm, act)
+
+
 class SerializedPooling(PointModule):
     def __init__(self, in_channels, out_channels, stride=2, norm_layer=None, act_layer=None, reduce="mean",
                  shuffle_orders=True, traceable=True):
@@ -168,11 +191,7 @@ class SerializedPooling(PointModule):
 
     def forward(self, x, coarse_level):
         x = SF.segment_mean(self.proj(x), coarse_level)
-        if self.norm is not None:
-            x = self.norm(x)
-        if self.act is not None:
-            x = self.act(x)
-        return x
+        return _norm_act(x, self.norm[0] if self.norm is not None else None, self.act)
 
 
 class SerializedUnpooling(PointModule):
@@ -187,8 +206,8 @@ class SerializedUnpooling(PointModule):
 
     def forward(self, x, skip, coarse_level):
         """returns (parent.feat, parent.sparse_conv_feat.features)"""
-        skip = self.proj_skip(skip)
-        return SF.unpool_add(skip, self.proj(x), coarse_level), skip
+        skip, up = _seq_lin_norm_act(self.proj_skip, skip), _seq_lin_norm_act(self.proj, x)
+        return SF.unpool_add(skip, up, coarse_level), skip
 
 
 class _Stem(nn.Module):
@@ -208,11 +227,7 @@ class Embedding(PointModule):
 
     def forward(self, feat, level):
         x = self.stem.conv(feat, level)
-        if hasattr(self.stem, "norm"):
-            x = self.stem.norm(x)
-        if hasattr(self.stem, "act"):
-            x = self.stem.act(x)
-        return x
+        return _norm_act(x, getattr(self.stem, "norm", None), getattr(self.stem, "act", None))
 
 
 class _Stage(nn.Module):
@@ -285,6 +300,43 @@ class PointTransformerV3(PointModule):
             perms.append(torch.randperm(K).tolist() if down.shuffle_orders else list(range(K)))
         return perms
 
+    def plan_specs(self):
+        """Everything the float pipeline will ask the plan for: (window specs, conv kernel sizes)."""
+        K = len(self.order)
+        wins, ks = [], [(0, 5)]
+        for s in range(self.num_stages):
+            enc = getattr(self.enc, f"enc{s}")
+            ks.append((s, 3))
+            for i in range(self.enc_depths[s]):
+                wins.append((s, i % K, getattr(enc, f"block{i}").attn.patch_size))
+        if not self.cls_mode:
+            for s in range(self.num_stages - 1):
+                dec = getattr(self.dec, f"dec{s}")
+                for i in range(self.dec_depths[s]):
+                    wins.append((s, i % K, getattr(dec, f"block{i}").attn.patch_size))
+        return wins, ks
+
+    def prepare_plan(self, data_dict, perms=None, stream=None):
+        """Build the integer plan of a batch ahead of time, optionally on a side stream so that its
+        device->host round trips (depth, pooled sizes) never wait for the float pipeline of the
+        previous step.  Pass the result as data_dict["plan"]."""
+        if "grid_coord" not in data_dict:
+            raise KeyError("prepare_plan needs grid_coord")
+        perms = perms if perms is not None else self.draw_perms()
+        if stream is None:
+            plan = build_plan(data_dict["grid_coord"], data_dict["offset"], self.order, self.stride, perms)
+            plan.materialize(*self.plan_specs())
+            return plan
+        # NB: no wait on the main stream here -- that would park the plan behind the previous step's whole
+        # backward.  The caller guarantees grid_coord / offset are already materialised (as a loader's
+        # copy stream would after its own event).
+        with torch.cuda.stream(stream):
+            plan = build_plan(data_dict["grid_coord"], data_dict["offset"], self.order, self.stride, perms)
+            plan.materialize(*self.plan_specs())
+            plan.ready_event = torch.cuda.Event()
+            plan.ready_event.record(stream)
+        return plan
+
     def forward(self, data_dict, perms=None):
         point = data_dict if isinstance(data_dict, Point) else Point(data_dict)
         feat = point["feat"]
@@ -301,8 +353,14 @@ class PointTransformerV3(PointModule):
             offset = point["offset"]  # derived lazily from batch
         # the fused conv consumes bf16: let each block hand the next one a bf16 copy of the residual stream
         self._want_copy = (RUNTIME["conv_dtype"] == torch.bfloat16)
-        plan = build_plan(point["grid_coord"], offset, self.order, self.stride,
-                          perms if perms is not None else self.draw_perms())
+        plan = point.get("plan", None)
+        if plan is None:
+            plan = build_plan(point["grid_coord"], offset, self.order, self.stride,
+                              perms if perms is not None else self.draw_perms())
+        elif plan.ready_event is not None:
+            torch.cuda.current_stream().wait_event(plan.ready_event)
+            plan.record_stream(torch.cuda.current_stream())
+            plan.ready_event = None
         levels = plan.levels
         x = self.embedding(feat, levels[0])
         skips = []

@@ -269,3 +269,41 @@ def test_fused_add_layernorm_against_torch(C, xdt, ydt, hdt):
     (o.float() * ch.cuda()).sum().backward()
     assert torch.allclose(tg.grad.float().cpu(), tr.grad, atol=gtol, rtol=2e-2)
     assert (gg.grad.cpu() - gr.grad).norm() <= (2e-3 if ydt == torch.float32 else 1e-2) * gr.grad.norm() + 1e-4
+
+
+@pytest.mark.parametrize("C,act", [(32, True), (768, True), (48, False)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("training", [True, False])
+def test_fused_batchnorm_gelu_against_torch(C, act, dtype, training):
+    from scenesplat_amd import functional as SF
+    g = torch.Generator().manual_seed(C + int(act))
+    n = 2111
+    x = (torch.randn(n, C, generator=g) * 1.7 + 0.3).to(dtype)
+    cot = torch.randn(n, C, generator=g)
+    def mk():
+        bn = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01)
+        with torch.no_grad():
+            bn.weight.copy_(1 + 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(1)))
+            bn.bias.copy_(0.1 * torch.randn(C, generator=torch.Generator().manual_seed(2)))
+            bn.running_mean.copy_(0.2 * torch.randn(C, generator=torch.Generator().manual_seed(3)))
+            bn.running_var.copy_(1 + 0.2 * torch.rand(C, generator=torch.Generator().manual_seed(4)))
+        return bn.train(training)
+    ref, dev = mk(), mk().cuda()
+    xr = x.float().clone().requires_grad_(True)
+    yr = ref(xr)
+    if act:
+        yr = F.gelu(yr)
+    (yr * cot).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    y = SF.batch_norm_act(xg, dev, act)
+    assert y.dtype == dtype
+    (y.float() * cot.cuda()).sum().backward()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert torch.allclose(y.float().cpu(), yr.detach(), atol=tol, rtol=tol)
+    assert torch.allclose(xg.grad.float().cpu(), xr.grad, atol=tol * 2, rtol=5e-2 if dtype == torch.bfloat16 else 1e-3)
+    rt = 2e-4 if dtype == torch.float32 else 8e-3
+    assert (dev.weight.grad.cpu() - ref.weight.grad).norm() <= rt * ref.weight.grad.norm() + 1e-4
+    assert (dev.bias.grad.cpu() - ref.bias.grad).norm() <= rt * ref.bias.grad.norm() + 1e-4
+    assert torch.allclose(dev.running_mean.cpu(), ref.running_mean, atol=1e-5, rtol=1e-4)
+    assert torch.allclose(dev.running_var.cpu(), ref.running_var, atol=1e-5, rtol=1e-4)
+    assert int(dev.num_batches_tracked) == int(ref.num_batches_tracked)
