@@ -47,62 +47,70 @@ __device__ __forceinline__ int cv_tr_off(int row, int chunk) {
   return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
 }
 
-template <typename OutT>
-__global__ void __launch_bounds__(CV_THREADS, 2)
+// WM x WN waves, each TM x TN sixteen-wide tiles: BM = 16*TM*WM sites, BN = 16*TN*WN channels per workgroup.
+//   <2,2,4,4>  128 x 128, 256 threads, ~79 KB LDS (2 workgroups / CU)   -- narrow layers (Cout < 256)
+//   <4,2,4,8>  256 x 256, 512 threads, ~156 KB LDS (1 workgroup / CU)   -- wide layers: half the L2->LDS bytes
+//              per FLOP (the 128 x 128 form moved 20 GB per dec0 call = 8.5 TB/s and was bound by it)
+template <typename OutT, int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(64 * WM * WN)
 k_subm_gemm(const unsigned short* __restrict__ in, const unsigned short* __restrict__ W, const float* __restrict__ bias,
             const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowperm, OutT* __restrict__ out, int n,
             int Cin, int Cout, int taps) {
-  constexpr int IMG = CV_BM * CV_BK * 2;   // 16 KB
-  __shared__ __attribute__((aligned(16))) char smem[4 * IMG];            // A0 B0 A1 B1
-  __shared__ int32_t nbr_s[CV_TG][CV_BM];
-  __shared__ int32_t rowid_s[CV_BM];
+  constexpr int THREADS = 64 * WM * WN, BM = 16 * TM * WM, BN = 16 * TN * WN;
+  constexpr int AIMG = BM * CV_BK * 2, BIMG = BN * CV_BK * 2;
+  constexpr int NLA = (BM * 8) / THREADS, NLB = (BN * 8) / THREADS;      // 16-byte chunks per thread per K-step
+  __shared__ __attribute__((aligned(16))) char smem[2 * (AIMG + BIMG)];   // A0 B0 A1 B1
+  __shared__ int32_t nbr_s[CV_TG][BM];
+  __shared__ int32_t rowid_s[BM];
   __shared__ int act_s[CV_TG];
   __shared__ unsigned mask_s;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, g = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * CV_BM, n0 = blockIdx.y * CV_BN;
-  if (tid < CV_BM) {
-    int r = m0 + tid;
-    rowid_s[tid] = r < n ? (rowperm ? rowperm[r] : r) : -1;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  for (int r = tid; r < BM; r += THREADS) {
+    int k = m0 + r;
+    rowid_s[r] = k < n ? (rowperm ? rowperm[k] : k) : -1;
   }
-  f32x4_t acc[4][4];
+  f32x4_t acc[TM][TN];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int ksteps = (Cin + CV_BK - 1) / CV_BK;
-  uint4 sa[4], sb[4];
+  uint4 sa[NLA], sb[NLB];
   auto stage_load = [&](int tt, int tap, int ci0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int c = i * CV_THREADS + tid;
-      int r = c >> 3, ch = c & 7;
-      int ci = ci0 + ch * 8;
-      uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < NLA; ++i) {
+      int c = i * THREADS + tid;
+      int r = c >> 3, ci = ci0 + (c & 7) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
       int src = nbr_s[tt][r];
-      if (src >= 0 && ci < Cin) va = *reinterpret_cast<const uint4*>(in + (int64_t)src * Cin + ci);
-      int co = n0 + r;
-      if (co < Cout && ci < Cin) vb = *reinterpret_cast<const uint4*>(W + ((int64_t)co * taps + tap) * Cin + ci);
-      sa[i] = va; sb[i] = vb;
+      if (src >= 0 && ci < Cin) v = *reinterpret_cast<const uint4*>(in + (int64_t)src * Cin + ci);
+      sa[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      int c = i * THREADS + tid;
+      int co = n0 + (c >> 3), ci = ci0 + (c & 7) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (co < Cout && ci < Cin) v = *reinterpret_cast<const uint4*>(W + ((int64_t)co * taps + tap) * Cin + ci);
+      sb[i] = v;
     }
   };
   auto stage_write = [&](int b) {
-    char* A = smem + b * 2 * IMG; char* B = A + IMG;
+    char* A = smem + b * (AIMG + BIMG); char* B = A + AIMG;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int c = i * CV_THREADS + tid;
-      int r = c >> 3, ch = c & 7;
-      *reinterpret_cast<uint4*>(A + cv_row_off(r, ch)) = sa[i];
-      *reinterpret_cast<uint4*>(B + cv_row_off(r, ch)) = sb[i];
-    }
+    for (int i = 0; i < NLA; ++i) { int c = i * THREADS + tid; *reinterpret_cast<uint4*>(A + cv_row_off(c >> 3, c & 7)) = sa[i]; }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) { int c = i * THREADS + tid; *reinterpret_cast<uint4*>(B + cv_row_off(c >> 3, c & 7)) = sb[i]; }
   };
   for (int tg = 0; tg < taps; tg += CV_TG) {
     const int nt = min(CV_TG, taps - tg);
     __syncthreads();                     // previous group's LDS reads are done
     if (tid == 0) mask_s = 0u;
     __syncthreads();
-    for (int e = tid; e < nt * CV_BM; e += CV_THREADS) {
-      int tt = e / CV_BM, r = e - tt * CV_BM;
+    for (int e = tid; e < nt * BM; e += THREADS) {
+      int tt = e / BM, r = e - tt * BM;
       int row = rowid_s[r];
       int v = row >= 0 ? nbr[(int64_t)(tg + tt) * n + row] : -1;
       nbr_s[tt][r] = v;
@@ -131,32 +139,32 @@ k_subm_gemm(const unsigned short* __restrict__ in, const unsigned short* __restr
         int tt = act_s[a_];
         stage_load(tt, tg + tt, k_ * CV_BK);
       }
-      const char* A = smem + b * 2 * IMG; const char* B = A + IMG;
+      const char* A = smem + b * (AIMG + BIMG); const char* B = A + AIMG;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf8_t af[4], bf[4];
+        bf8_t af[TM], bf[TN];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) af[mi] = cv_lds_b128(A, cv_row_off(64 * wm + 16 * mi + lq, 4 * ks + g));
+        for (int mi = 0; mi < TM; ++mi) af[mi] = cv_lds_b128(A, cv_row_off(16 * TM * wm + 16 * mi + lq, 4 * ks + g));
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) bf[ni] = cv_lds_b128(B, cv_row_off(64 * wn + 16 * ni + lq, 4 * ks + g));
+        for (int ni = 0; ni < TN; ++ni) bf[ni] = cv_lds_b128(B, cv_row_off(16 * TN * wn + 16 * ni + lq, 4 * ks + g));
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = MFMA16(bf[ni], af[mi], acc[mi][ni]);   // C^T: rows = channels
+          for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = MFMA16(bf[ni], af[mi], acc[mi][ni]);   // C^T: rows = channels
       }
       if (it + 1 < iters) stage_write(b ^ 1);
       __syncthreads();
     }
   }
-  // epilogue: acc[mi][ni] holds C^T: element r = channel n0 + 64wn + 16ni + 4g + r of site 64wm + 16mi + lq
+  // epilogue: acc[mi][ni] holds C^T: element r = channel n0 + 16TN*wn + 16ni + 4g + r of site 16TM*wm + 16mi + lq
   // -> one 8-byte (bf16) / 16-byte (f32) store per tile instead of four 2-byte ones
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int row = rowid_s[64 * wm + 16 * mi + lq];
+  for (int mi = 0; mi < TM; ++mi) {
+    const int row = rowid_s[16 * TM * wm + 16 * mi + lq];
     if (row < 0) continue;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int col = n0 + 64 * wn + 16 * ni + 4 * g;
+    for (int ni = 0; ni < TN; ++ni) {
+      const int col = n0 + 16 * TN * wn + 16 * ni + 4 * g;
       if (col + 3 < Cout && (Cout & 3) == 0) {
         float4 v = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
         if (bias) { float4 bv = *reinterpret_cast<const float4*>(bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
@@ -317,19 +325,29 @@ k_subm_wgrad(const unsigned short* __restrict__ in, const unsigned short* __rest
     }
 }
 
+template <typename OutT>
+static int subm_gemm_launch(const unsigned short* x, const unsigned short* w, const float* bias, const int32_t* nbr,
+                            const int32_t* rowperm, OutT* out, int n, int cin, int cout, int taps, hipStream_t stream) {
+  // the 256 x 256 form needs enough tiles to fill 256 CUs at one workgroup each
+  if (cout >= 256 && (int64_t)ss_div_up(n, 256) * ss_div_up(cout, 256) >= 256) {
+    dim3 g(ss_div_up(n, 256), ss_div_up(cout, 256)), b(512);
+    SS_LAUNCH((k_subm_gemm<OutT, 4, 2, 4, 8>), g, b, 0, stream, x, w, bias, nbr, rowperm, out, n, cin, cout, taps);
+  } else {
+    dim3 g(ss_div_up(n, 128), ss_div_up(cout, 128)), b(256);
+    SS_LAUNCH((k_subm_gemm<OutT, 2, 2, 4, 4>), g, b, 0, stream, x, w, bias, nbr, rowperm, out, n, cin, cout, taps);
+  }
+  return SS_OK;
+}
+
 extern "C" int ss_subm_conv_fwd(const void* in, const void* weight, const float* bias, const int32_t* nbr,
                                 const int32_t* rowperm, void* out, int64_t n, int cin, int cout, int taps, int out_dtype,
                                 hipStream_t stream) {
   if (n < 0 || cin <= 0 || cout <= 0 || taps <= 0 || (cin & 7) || n >= (1LL << 31)) return SS_ERR_ARG;
   if (n == 0) return SS_OK;
-  dim3 g(ss_div_up(n, CV_BM), ss_div_up(cout, CV_BN)), b(CV_THREADS);
   const unsigned short* x = (const unsigned short*)in; const unsigned short* w = (const unsigned short*)weight;
-  if (out_dtype == SS_BF16)
-    SS_LAUNCH(k_subm_gemm<unsigned short>, g, b, 0, stream, x, w, bias, nbr, rowperm, (unsigned short*)out, (int)n, cin, cout, taps);
-  else if (out_dtype == SS_F32)
-    SS_LAUNCH(k_subm_gemm<float>, g, b, 0, stream, x, w, bias, nbr, rowperm, (float*)out, (int)n, cin, cout, taps);
-  else return SS_ERR_ARG;
-  return SS_OK;
+  if (out_dtype == SS_BF16) return subm_gemm_launch<unsigned short>(x, w, bias, nbr, rowperm, (unsigned short*)out, (int)n, cin, cout, taps, stream);
+  if (out_dtype == SS_F32) return subm_gemm_launch<float>(x, w, bias, nbr, rowperm, (float*)out, (int)n, cin, cout, taps, stream);
+  return SS_ERR_ARG;
 }
 
 extern "C" int ss_subm_conv_wgrad(const void* in, const void* dout, const int32_t* nbr, const int32_t* rowperm,
