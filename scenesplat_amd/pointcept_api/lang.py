@@ -105,19 +105,19 @@ class AggregatedContrastiveLoss(nn.Module):
         in_b = (rank - starts[cls]) >= half[cls]
         row_group = torch.where(cls < Cc, 2 * cls + in_b.long(), torch.full_like(cls, 2 * Cc)).to(torch.int32)
         G = _GroupSum.apply(pred.float(), order.contiguous(), ptr, 2 * Cc, row_group.contiguous())
-        A, B = F.normalize(G[0::2], p=2, dim=1), F.normalize(G[1::2], p=2, dim=1)
         used = (counts[:Cc] >= self.min_count) & (half[:Cc] > 0)
         nused = used.sum()
-        neg = torch.finfo(torch.float32).min
-        logits = (A @ B.t()) / self.temperature
         colmask = used.unsqueeze(0)
+        with torch.autocast("cuda", enabled=False):      # <= 256 x 256 logits: keep the tiny tail in fp32
+            A, B = F.normalize(G[0::2].float(), p=2, dim=1), F.normalize(G[1::2].float(), p=2, dim=1)
+            logits = (A @ B.t()) / self.temperature
 
-        def ce(lg):
-            lg = torch.where(colmask, lg, torch.full_like(lg, neg))
-            per = torch.logsumexp(lg, dim=1) - lg.diagonal()
-            return (per * used).sum() / nused.clamp(min=1)
+            def ce(lg):
+                lg = torch.where(colmask, lg, torch.full_like(lg, -1e30))
+                per = torch.logsumexp(lg, dim=1) - lg.diagonal()
+                return (per * used).sum() / nused.clamp(min=1)
 
-        loss = (ce(logits) + ce(logits.t())) / 2.0
+            loss = (ce(logits) + ce(logits.t())) / 2.0
         if self.reduction == "sum":
             loss = loss * nused
         return self.loss_weight * loss * (nused > 0)
