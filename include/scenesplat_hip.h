@@ -124,6 +124,12 @@ int ss_bn_act_bwd_apply(const void* dy, int dy_dtype, const void* x, int x_dtype
                         const float* gamma, const float* beta, int act, const float* c1, const float* c2, void* dx,
                         int dx_dtype, int64_t n, int channels, ss_stream_t stream);
 
+/* ---- open-vocabulary scan (evaluator.py:793-800, test.py:335-351) ----------------------------------------
+ * feat (n, dim) bf16 unit rows, text (num_classes <= 256, dim) bf16.  max_prob/argmax (n) = max / arg-max of
+ * sigmoid(feat text^T) (ties: lowest class), and/or pred_accum[idx ? idx[i] : i][c] += sigmoid(logit). */
+int ss_feat_text_scan(const void* feat_bf16, const void* text_bf16, int64_t n, int dim, int num_classes, float* max_prob,
+                      int32_t* argmax, const int32_t* idx, float* pred_accum, ss_stream_t stream);
+
 /* ---- row movement ------------------------------------------------------------------------ */
 int ss_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_dst, int64_t row_bytes, ss_stream_t stream);
 int ss_scatter_rows(const void* src, const int32_t* idx, void* dst, int64_t n_src, int64_t row_bytes, ss_stream_t stream);

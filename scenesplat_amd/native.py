@@ -286,6 +286,27 @@ def bn_act_bwd(dy, x, mean, rstd, gamma, beta, act, training):
     return dx, sdzx, sdz
 
 
+# ---- open-vocabulary scan ----------------------------------------------------------------------------
+def feat_text_scan(feat, text, want_max=True, idx=None, pred_accum=None):
+    """feat (n, D), text (C, D) -> (max_prob (n) f32, argmax (n) int32) and/or pred_accum[idx] += sigmoid(feat text^T)."""
+    f = _req(feat.to(torch.bfloat16).contiguous(), torch.bfloat16, "feat")
+    t = _req(text.to(torch.bfloat16).contiguous(), torch.bfloat16, "text")
+    n, D = f.shape
+    C = t.shape[0]
+    if t.shape[1] != D or D % 8 or C > 256:
+        raise RuntimeError("feat_text_scan: need matching dim (multiple of 8) and <= 256 classes")
+    mp = torch.empty(n, dtype=torch.float32, device=f.device) if want_max else None
+    am = torch.empty(n, dtype=torch.int32, device=f.device) if want_max else None
+    if pred_accum is not None:
+        _req(pred_accum, torch.float32, "pred_accum")
+        if pred_accum.shape[1] != C:
+            raise RuntimeError("pred_accum must be (rows, num_classes)")
+    if idx is not None:
+        _req(idx, torch.int32, "idx", (n,))
+    check(lib().ss_feat_text_scan(_p(f), _p(t), n, D, C, _p(mp), _p(am), _p(idx), _p(pred_accum), _stream()), "ss_feat_text_scan")
+    return mp, am
+
+
 # ---- rows ------------------------------------------------------------------------------------
 def gather_rows(src, idx, out=None):
     """out[i] = src[idx[i]] (zero row where idx < 0).  src (m, C)."""

@@ -307,3 +307,27 @@ def test_fused_batchnorm_gelu_against_torch(C, act, dtype, training):
     assert torch.allclose(dev.running_mean.cpu(), ref.running_mean, atol=1e-5, rtol=1e-4)
     assert torch.allclose(dev.running_var.cpu(), ref.running_var, atol=1e-5, rtol=1e-4)
     assert int(dev.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+@pytest.mark.parametrize("C", [6, 20, 100, 160, 200])
+def test_open_vocab_scan_against_reference_math(C):
+    """feat x text^T -> sigmoid -> max/argmax (evaluator.py:793-800) and fragment accumulation (test.py:343-351),
+    with the reference's own SigLIP2 text-embedding shapes (6..200 x 768)."""
+    from scenesplat_amd import native as nv
+    g = torch.Generator().manual_seed(C)
+    n, D = 3001, 768
+    feat = F.normalize(torch.randn(n, D, generator=g), dim=1).to(torch.bfloat16)
+    text = F.normalize(torch.randn(C, D, generator=g), dim=1).to(torch.bfloat16)
+    logits = feat.float() @ text.float().t()
+    probs = torch.sigmoid(logits)
+    mp, am = nv.feat_text_scan(feat.cuda(), text.cuda())
+    rmax, rarg = probs.max(1)
+    assert torch.allclose(mp.cpu(), rmax, atol=2e-4)
+    agree = (am.cpu().long() == rarg)
+    assert agree.float().mean() > 0.999 and torch.allclose(probs[torch.arange(n), am.cpu().long()], rmax, atol=2e-4)
+    idx = torch.randperm(5000, generator=g)[:n].to(torch.int32)
+    pred = torch.zeros(5000, C, device="cuda")
+    nv.feat_text_scan(feat.cuda(), text.cuda(), want_max=False, idx=idx.cuda(), pred_accum=pred)
+    nv.feat_text_scan(feat.cuda(), text.cuda(), want_max=False, idx=idx.cuda(), pred_accum=pred)
+    ref = torch.zeros(5000, C); ref[idx.long()] = 2 * probs
+    assert torch.allclose(pred.cpu(), ref, atol=5e-4)
