@@ -34,6 +34,9 @@ def parse():
     ap.add_argument("--n-side", type=int, default=256, help="room side; 256 -> 102,400 Gaussians")
     ap.add_argument("--attn", default="auto", choices=["auto", "simt", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a one-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--cpu-n-side", type=int, default=128, help="room side of the CPU-baseline sample (128 -> 25,600 Gaussians, ~10-20 s on 16 cores)")
     return ap.parse_args()
 
@@ -63,9 +66,19 @@ def roofline_probes(model, data, impl):
     qkv = torch.randn(lv.n, 3 * C, device="cuda", generator=g).to(torch.bfloat16)
     ms = event_time_ms(lambda: nv.window_attn_fwd(qkv, win, H, (C // H) ** -0.5, impl), 5)
     flops = sum(4.0 * L * L * (C // H) for L in [K] * win.num_windows) * H
-    attn = dict(bound="mfma", kernel="window_attn_fwd(dec0: %d windows x %d heads, K=%d, d=%d)" % (win.num_windows, H, K, C // H),
+    # HBM-side bytes per launch of this kernel at this shape, from the committed PMC passes
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied; scripts/gpu_pmc.sh)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if lv.n == 102400:
+            traffic = pmc["k_attn_fwd_mfma<48>@dec0"]["traffic_bytes_corrected"]
+    except Exception:
+        pass
+    attn = dict(bound="mfma", kernel="k_attn_fwd_mfma<48> (dec0: %d windows x %d heads, K=%d, d=%d)" % (win.num_windows, H, K, C // H),
                 achieved=flops / (ms * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
-                frac=flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, traffic=None, ms=ms)
+                frac=flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, traffic=traffic, traffic_unit="bytes/launch (PMC)",
+                algorithmic_flops=flops, ms=ms)
     x = torch.randn(lv.n, C, device="cuda", generator=g).to(torch.bfloat16)
     idx = lv.order_row(0)
     out = torch.empty_like(x)
@@ -108,11 +121,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from scenesplat_amd import native as nv
     from scenesplat_amd.pointcept_api import MODELS, RUNTIME
@@ -130,7 +148,7 @@ def main():
     if world > 1:
         # DDP as the reference builds it (engines/defaults.py:13-34): broadcast_buffers=False
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
-                                                        gradient_as_bucket_view=True)
+                                                        gradient_as_bucket_view=True, bucket_cap_mb=100)
     data = {k: v.to(dev) for k, v in room_chunk(n_side=args.n_side, seed=rank, lang_dim=0).items()}
     n = data["feat"].shape[0]
     cot = torch.randn(n, LANG_PTV3["dec_channels"][0], device=dev, generator=torch.Generator(device=dev).manual_seed(7))
