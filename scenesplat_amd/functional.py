@@ -35,20 +35,20 @@ def window_attention(qkv, win, num_heads, scale, impl=nv.ATTN_SIMT):
 
 class _SegmentMean(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src, level):
+    def forward(ctx, src, level, mean):
         src = src.contiguous()
-        ctx.level = level
-        return nv.segment_reduce(src, level.indices, level.idx_ptr, level.n, True)
+        ctx.level, ctx.mean = level, mean
+        return nv.segment_reduce(src, level.indices, level.idx_ptr, level.n, mean)
 
     @staticmethod
     def backward(ctx, dout):
         lv = ctx.level
-        return nv.segment_bcast(dout.contiguous(), lv.cluster, lv.idx_ptr, True), None
+        return nv.segment_bcast(dout.contiguous(), lv.cluster, lv.idx_ptr, ctx.mean), None, None
 
 
-def segment_mean(src, level):
-    """Pool rows of the finer level into `level` (the coarser one): mean over each cluster."""
-    return _SegmentMean.apply(src, level)
+def segment_mean(src, level, mean=True):
+    """Pool rows of the finer level into `level` (the coarser one): mean (or sum) over each cluster."""
+    return _SegmentMean.apply(src, level, mean)
 
 
 class _UnpoolAdd(torch.autograd.Function):

@@ -181,8 +181,9 @@ class SerializedPooling(PointModule):
     def __init__(self, in_channels, out_channels, stride=2, norm_layer=None, act_layer=None, reduce="mean",
                  shuffle_orders=True, traceable=True):
         super().__init__()
-        if reduce != "mean":
-            raise NotImplementedError("only the 'mean' grid pool is on the HIP path (the reference default)")
+        if reduce not in ("mean", "sum"):
+            raise NotImplementedError("grid pool reduce 'min'/'max' is not on the HIP path (every reference config uses 'mean')")
+        self.reduce = reduce
         self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
         self.shuffle_orders = shuffle_orders
         self.proj = nn.Linear(in_channels, out_channels)
@@ -190,7 +191,7 @@ class SerializedPooling(PointModule):
         self.act = act_layer() if act_layer is not None else None
 
     def forward(self, x, coarse_level):
-        x = SF.segment_mean(self.proj(x), coarse_level)
+        x = SF.segment_mean(self.proj(x), coarse_level, mean=(self.reduce == "mean"))
         return _norm_act(x, self.norm[0] if self.norm is not None else None, self.act)
 
 

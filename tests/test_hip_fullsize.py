@@ -1,0 +1,132 @@
+"""GPU, BASELINE full size (room-102400 and a 1M-Gaussian region): size-independent properties of the HIP path
+where the oracle would take too long -- sortedness, permutation round trips, pooled level sizes pinned by
+SURVEY 8d, window coverage, linearity of the float kernels, idempotence of the plan."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ORD = ("z", "z-trans", "hilbert", "hilbert-trans")
+
+
+@pytest.fixture(scope="module")
+def room():
+    from scenesplat_amd.plan import build_plan
+    from scenesplat_amd.synthetic import room_chunk
+    data = room_chunk(256, 0, lang_dim=0)
+    plan = build_plan(data["grid_coord"].cuda(), data["offset"].cuda(), ORD, (2, 2, 2))
+    return data, plan
+
+
+def test_room_102400_level_sizes_and_orders(room):
+    data, plan = room
+    assert [lv.n for lv in plan.levels] == [102400, 25600, 6400, 1600]
+    assert [lv.depth for lv in plan.levels] == [8, 7, 6, 5]
+    for lv in plan.levels:
+        ar = torch.arange(lv.n, device="cuda", dtype=torch.int32)
+        for j in range(4):
+            o, inv, c = lv.order_row(j).long(), lv.inverse_row(j).long(), lv.code_row(j)
+            sc = c[o]
+            assert bool((sc[1:] > sc[:-1]).all())                                 # strictly sorted: unique voxels
+            assert torch.equal(inv[o].int(), ar) and torch.equal(o[inv].int(), ar)   # permutation round trip
+            assert torch.equal(lv.codes_sorted[lv.curves[j]], sc)
+        assert not lv.has_duplicates
+        nbr = lv.neighbors(3)
+        assert torch.equal(nbr[13], ar)                                         # centre tap = self
+        # rulebook symmetry: nbr[t][i] = j  <=>  nbr[26-t][j] = i
+        for t in (0, 5, 12, 20):
+            i = torch.nonzero(nbr[t] >= 0).squeeze(1)
+            assert torch.equal(nbr[26 - t][nbr[t][i].long()].long(), i)
+        assert abs(float((nbr >= 0).float().sum() / lv.n) - 9.0) < 0.1          # ~9 occupied taps/site on surfaces
+    for fine, coarse in zip(plan.levels[:-1], plan.levels[1:]):
+        cnt = torch.bincount(coarse.cluster.long(), minlength=coarse.n)
+        ptr = coarse.idx_ptr[:coarse.n + 1].long()
+        assert torch.equal(cnt, ptr[1:] - ptr[:-1]) and int(ptr[-1]) == fine.n
+        assert torch.equal(coarse.grid_coord[coarse.cluster.long()], fine.grid_coord >> 1)
+
+
+def test_room_102400_window_index_covers_every_row_once(room):
+    data, plan = room
+    lv = plan.levels[0]
+    for j in range(4):
+        w = lv.window(j, 1024)
+        assert w.num_windows == 100 and w.n_pad == 102400
+        canon = w.sidx[w.sidx >= 0].long()
+        assert torch.equal(torch.sort(canon).values, torch.arange(lv.n, device="cuda"))
+    # a size that needs padding: K = 1000 -> 103 windows, 600 borrowed slots
+    w = lv.window(0, 1000)
+    assert w.n_pad == 103000 and int((w.sidx < 0).sum()) == 600
+    assert torch.equal(torch.sort(w.sidx[w.sidx >= 0].long()).values, torch.arange(lv.n, device="cuda"))
+    assert torch.equal(torch.sort(-1 - w.sidx[w.sidx < 0]).values.long(), torch.arange(600, device="cuda"))
+
+
+def test_full_size_attention_properties(room):
+    """softmax rows sum to 1 (V = const -> out = const) and linearity in V, K = 1024, d = 48, 16 heads."""
+    from scenesplat_amd import native as nv
+    data, plan = room
+    lv = plan.levels[0]
+    win = lv.window(2, 1024)
+    C, H = 768, 16
+    g = torch.Generator(device="cuda").manual_seed(1)
+    qkv = torch.randn(lv.n, 3 * C, device="cuda", generator=g).to(torch.bfloat16)
+    qkv1 = qkv.clone(); qkv1[:, 2 * C:] = 1.0
+    o1, _ = nv.window_attn_fwd(qkv1, win, H, 48 ** -0.5, nv.ATTN_MFMA)
+    assert (o1.float() - 1.0).abs().max() < 1e-2
+    va, vb = qkv[:, 2 * C:].clone(), torch.randn(lv.n, C, device="cuda", generator=g).to(torch.bfloat16)
+    qa, qb, qs = qkv.clone(), qkv.clone(), qkv.clone()
+    qb[:, 2 * C:] = vb; qs[:, 2 * C:] = (va.float() + vb.float()).to(torch.bfloat16)
+    oa, _ = nv.window_attn_fwd(qa, win, H, 48 ** -0.5, nv.ATTN_MFMA)
+    ob, _ = nv.window_attn_fwd(qb, win, H, 48 ** -0.5, nv.ATTN_MFMA)
+    os_, lse = nv.window_attn_fwd(qs, win, H, 48 ** -0.5, nv.ATTN_MFMA)
+    assert (os_.float() - oa.float() - ob.float()).abs().max() < 6e-2
+    assert torch.isfinite(lse).all()
+
+
+def test_full_size_conv_linearity_and_adjoint(room):
+    """conv(a x + y) = a conv(x) + conv(y); <conv(x), g> = <x, dgrad(g)> (the dgrad kernel is the adjoint)."""
+    from scenesplat_amd import native as nv
+    data, plan = room
+    lv = plan.levels[1]
+    C = 256
+    g = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn(lv.n, C, device="cuda", generator=g).to(torch.bfloat16)
+    y = torch.randn(lv.n, C, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(C, 27, C, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    nbr, perm = lv.neighbors(3), lv.conv_rowperm()
+    f = lambda t: nv.subm_conv_fwd(t, w, None, nbr, perm, torch.float32)
+    lhs = f((2 * x.float() + y.float()).to(torch.bfloat16))
+    rhs = 2 * f(x) + f(y)
+    assert (lhs - rhs).norm() / rhs.norm() < 1e-2
+    gout = torch.randn(lv.n, C, device="cuda", generator=g).to(torch.bfloat16)
+    wt = w.flip(1).permute(2, 1, 0).contiguous()
+    dx = nv.subm_conv_fwd(gout, wt, None, nbr, perm, torch.float32)
+    a = (f(x) * gout.float()).sum(); b = (x.float() * dx).sum()
+    assert abs(a - b) / abs(a) < 2e-3
+    # wgrad is bilinear: dW(x, 2g) = 2 dW(x, g)
+    blocks = lv.conv_blocks(3)
+    d1 = nv.subm_conv_wgrad(x, gout, nbr, perm, blocks)
+    d2 = nv.subm_conv_wgrad(x, (2 * gout.float()).to(torch.bfloat16), nbr, perm, blocks)
+    assert (d2 - 2 * d1).norm() / d1.norm() < 1e-3
+
+
+def test_million_gaussian_region_plan_and_scan():
+    """BASELINE config 5 scale: ~1M unique voxels, depth 9; argsort / inverse round trip and the fused scan."""
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.plan import build_plan
+    g = torch.Generator().manual_seed(3)
+    lin = torch.randperm(400 * 400 * 160, generator=g)[:1_000_000]
+    gc = torch.stack([lin // (400 * 160), (lin // 160) % 400, lin % 160], 1)
+    plan = build_plan(gc.cuda(), torch.tensor([600_000, 1_000_000]).cuda(), ORD, (2,))
+    lv = plan.levels[0]
+    assert lv.depth == 9 and lv.n == 1_000_000
+    for j in range(4):
+        sc = lv.code_row(j)[lv.order_row(j).long()]
+        assert bool((sc[1:] > sc[:-1]).all())
+    assert torch.equal(lv.inverse_row(1)[lv.order_row(1).long()], torch.arange(lv.n, device="cuda", dtype=torch.int32))
+    assert bool((lv.batch[:600_000] == 0).all()) and bool((lv.batch[600_000:] == 1).all())
+    feat = torch.nn.functional.normalize(torch.randn(1_000_000, 768, device="cuda"), dim=1).to(torch.bfloat16)
+    text = torch.nn.functional.normalize(torch.randn(160, 768, device="cuda"), dim=1).to(torch.bfloat16)
+    mp, am = nv.feat_text_scan(feat, text)
+    sub = slice(123_000, 125_000)
+    ref = torch.sigmoid(feat[sub].float() @ text.float().t()).max(1)
+    assert torch.allclose(mp[sub], ref.values, atol=3e-4) and (am[sub].long() == ref.indices).float().mean() > 0.995
