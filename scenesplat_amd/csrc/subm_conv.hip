@@ -26,6 +26,12 @@ typedef __attribute__((address_space(3))) s4_t lds_s4_t;
 #define CV_BM 128
 #define CV_BN 128
 #define CV_BK 64
+#ifndef SS_CONV_DMA_SMALL
+#define SS_CONV_DMA_SMALL false
+#endif
+#ifndef SS_CONV_DMA_BIG
+#define SS_CONV_DMA_BIG false
+#endif
 #define CV_TG 27   // taps per rulebook group held in LDS (27 keeps the workgroup under 80 KB: 2 per CU)
 
 __device__ __forceinline__ bf8_t cv_as_bf8(uint4 v) { return __builtin_bit_cast(bf8_t, v); }
@@ -51,7 +57,18 @@ __device__ __forceinline__ int cv_tr_off(int row, int chunk) {
 //   <2,2,4,4>  128 x 128, 256 threads, ~79 KB LDS (2 workgroups / CU)   -- narrow layers (Cout < 256)
 //   <4,2,4,8>  256 x 256, 512 threads, ~156 KB LDS (1 workgroup / CU)   -- wide layers: half the L2->LDS bytes
 //              per FLOP (the 128 x 128 form moved 20 GB per dec0 call = 8.5 TB/s and was bound by it)
-template <typename OutT, int WM, int WN, int TM, int TN>
+__device__ uint4 g_zero_row[8];   // 128 zero bytes: the source of every missing-neighbour / out-of-range LDS-DMA piece
+
+__device__ __forceinline__ void cv_glds16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// DMA = true: tiles are filled by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction = 8 rows x 128 B):
+// the gather is the per-lane SOURCE address, the XOR swizzle is applied to the source chunk index, the LDS image
+// stays lane-linear; no staging VGPRs and no ds_write traffic (the register path was limited by the ~79 B/clk
+// VGPR->LDS store path).  The __syncthreads() that ends a K-step drains vmcnt, so the next tile has landed.
+template <typename OutT, int WM, int WN, int TM, int TN, bool DMA>
 __global__ void __launch_bounds__(64 * WM * WN)
 k_subm_gemm(const unsigned short* __restrict__ in, const unsigned short* __restrict__ W, const float* __restrict__ bias,
             const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowperm, OutT* __restrict__ out, int n,
@@ -77,7 +94,25 @@ k_subm_gemm(const unsigned short* __restrict__ in, const unsigned short* __restr
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int ksteps = (Cin + CV_BK - 1) / CV_BK;
-  uint4 sa[NLA], sb[NLB];
+  uint4 sa[DMA ? 1 : NLA], sb[DMA ? 1 : NLB];
+  auto stage_dma = [&](int b, int tt, int tap, int ci0) {
+    char* A = smem + b * (AIMG + BIMG); char* B = A + AIMG;
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+      int c = i * THREADS + tid;
+      int r = c >> 3, ci = ci0 + (((c & 7) ^ ((r >> 1) & 7)) << 3);      // LDS slot (r, c&7) holds logical chunk slot ^ swz(r)
+      int src = nbr_s[tt][r];
+      const void* g = (src >= 0 && ci < Cin) ? (const void*)(in + (int64_t)src * Cin + ci) : (const void*)g_zero_row;
+      cv_glds16(g, A + (c & ~63) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      int c = i * THREADS + tid;
+      int r = c >> 3, co = n0 + r, ci = ci0 + (((c & 7) ^ ((r >> 1) & 7)) << 3);
+      const void* g = (co < Cout && ci < Cin) ? (const void*)(W + ((int64_t)co * taps + tap) * Cin + ci) : (const void*)g_zero_row;
+      cv_glds16(g, B + (c & ~63) * 16);
+    }
+  };
   auto stage_load = [&](int tt, int tap, int ci0) {
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
@@ -128,16 +163,20 @@ k_subm_gemm(const unsigned short* __restrict__ in, const unsigned short* __restr
     if (iters == 0) continue;
     {
       int tt = act_s[0];
-      stage_load(tt, tg + tt, 0);
-      stage_write(0);
+      if (DMA) stage_dma(0, tt, tg + tt, 0);
+      else { stage_load(tt, tg + tt, 0); stage_write(0); }
     }
     __syncthreads();
     for (int it = 0; it < iters; ++it) {
       const int b = it & 1;
       if (it + 1 < iters) {
-        int a_ = (it + 1) / ksteps, k_ = (it + 1) - a_ * ksteps;
+        // channel chunk OUTER, tap INNER: the ~9-13 active taps of a tile gather (almost) the same neighbour
+        // rows, so one 128-byte column slice of them (tile rows x 128 B ~ 40 KB per CU) stays L2-resident
+        // across the taps instead of streaming every tap's full rows from the Infinity Cache
+        int k_ = (it + 1) / nact, a_ = (it + 1) - k_ * nact;
         int tt = act_s[a_];
-        stage_load(tt, tg + tt, k_ * CV_BK);
+        if (DMA) stage_dma(b ^ 1, tt, tg + tt, k_ * CV_BK);
+        else stage_load(tt, tg + tt, k_ * CV_BK);
       }
       const char* A = smem + b * (AIMG + BIMG); const char* B = A + AIMG;
 #pragma unroll
@@ -152,7 +191,7 @@ k_subm_gemm(const unsigned short* __restrict__ in, const unsigned short* __restr
 #pragma unroll
           for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = MFMA16(bf[ni], af[mi], acc[mi][ni]);   // C^T: rows = channels
       }
-      if (it + 1 < iters) stage_write(b ^ 1);
+      if (!DMA && it + 1 < iters) stage_write(b ^ 1);
       __syncthreads();
     }
   }
@@ -216,18 +255,24 @@ extern "C" int ss_subm_block_lists(const int32_t* nbr, const int32_t* rowperm, i
   return SS_OK;
 }
 
-// dW[co][t][ci] += sum over this workgroup's share of the tap's ACTIVE 64-site blocks
-__global__ void __launch_bounds__(CV_THREADS, 2)
+// dW[co][t][ci] += sum over this workgroup's share of the tap's ACTIVE 64-site blocks.
+// WM x WN waves of TM x TN tiles: <2,2,4,4> = 128 x 128 (narrow layers), <2,4,8,4> = 256 x 256 / 8 waves (wide).
+template <int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(64 * WM * WN)
 k_subm_wgrad(const unsigned short* __restrict__ in, const unsigned short* __restrict__ dout,
              const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowperm, const int32_t* __restrict__ blk_count,
              const int32_t* __restrict__ blk_list, float* __restrict__ dW, int n, int Cin, int Cout, int taps, int ntiles_n,
              int nblocks_total) {
-  constexpr int IMG = 64 * 256;   // 64 sites x 128 cols bf16 = 16 KB
-  __shared__ __attribute__((aligned(16))) char smem[4 * IMG];   // A0 B0 A1 B1
+  constexpr int THREADS = 64 * WM * WN, BMc = 16 * TM * WM, BNc = 16 * TN * WN;
+  constexpr int ARB = BMc * 2, BRB = BNc * 2;              // row bytes of the [site][col] images
+  constexpr int AIMG = 64 * ARB, BIMG = 64 * BRB;
+  constexpr int ACH = BMc / 8, BCH = BNc / 8;               // 16-byte chunks per row
+  constexpr int NLA = (64 * ACH) / THREADS, NLB = (64 * BCH) / THREADS;
+  __shared__ __attribute__((aligned(16))) char smem[2 * (AIMG + BIMG)];   // A0 B0 A1 B1
   __shared__ int32_t isite_s[2][64], jsite_s[2][64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, g = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = (blockIdx.x / ntiles_n) * 128, n0 = (blockIdx.x % ntiles_n) * 128;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = (blockIdx.x / ntiles_n) * BMc, n0 = (blockIdx.x % ntiles_n) * BNc;
   const int tap = blockIdx.y;
   const int cnt = blk_count[tap];
   const int per = (cnt + gridDim.z - 1) / gridDim.z;
@@ -235,12 +280,14 @@ k_subm_wgrad(const unsigned short* __restrict__ in, const unsigned short* __rest
   const int nblk = end - beg;
   if (nblk <= 0) return;
   const int32_t* list = blk_list + (int64_t)tap * nblocks_total + beg;
-  f32x4_t acc[4][4];
+  // plain [site][cols] image, 16-byte chunks XOR-swizzled inside each group of 16 for conflict-free transposed reads
+  auto img_off = [](int row, int ch, int rb) { return row * rb + ((((ch & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3))) | (ch & ~15)) << 4); };
+  f32x4_t acc[TM][TN];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  uint4 sa[4], sb[4];
+    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  uint4 sa[NLA], sb[NLB];
   auto index_load = [&](int b, int blk) {      // wave 0: site ids of the block
     if (tid < 64) {
       int k = list[blk] * 64 + tid;
@@ -251,28 +298,29 @@ k_subm_wgrad(const unsigned short* __restrict__ in, const unsigned short* __rest
   };
   auto stage_load = [&](int b) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int c = i * CV_THREADS + tid;
-      int r = c >> 4, ch = c & 15;
-      uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
-      int si = isite_s[b][r], sj = jsite_s[b][r];
-      int co = m0 + ch * 8, ci = n0 + ch * 8;
-      if (sj >= 0) {
-        if (co < Cout) va = *reinterpret_cast<const uint4*>(dout + (int64_t)si * Cout + co);
-        if (ci < Cin) vb = *reinterpret_cast<const uint4*>(in + (int64_t)sj * Cin + ci);
-      }
-      sa[i] = va; sb[i] = vb;
+    for (int i = 0; i < NLA; ++i) {
+      int c = i * THREADS + tid;
+      int r = c / ACH, co = m0 + (c % ACH) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (jsite_s[b][r] >= 0 && co < Cout) v = *reinterpret_cast<const uint4*>(dout + (int64_t)isite_s[b][r] * Cout + co);
+      sa[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      int c = i * THREADS + tid;
+      int r = c / BCH, ci = n0 + (c % BCH) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      int sj = jsite_s[b][r];
+      if (sj >= 0 && ci < Cin) v = *reinterpret_cast<const uint4*>(in + (int64_t)sj * Cin + ci);
+      sb[i] = v;
     }
   };
   auto stage_write = [&](int b) {
-    char* A = smem + b * 2 * IMG; char* B = A + IMG;
+    char* A = smem + b * (AIMG + BIMG); char* B = A + AIMG;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int c = i * CV_THREADS + tid;
-      int r = c >> 4, ch = c & 15;
-      *reinterpret_cast<uint4*>(A + cv_tr_off(r, ch)) = sa[i];
-      *reinterpret_cast<uint4*>(B + cv_tr_off(r, ch)) = sb[i];
-    }
+    for (int i = 0; i < NLA; ++i) { int c = i * THREADS + tid; *reinterpret_cast<uint4*>(A + img_off(c / ACH, c % ACH, ARB)) = sa[i]; }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) { int c = i * THREADS + tid; *reinterpret_cast<uint4*>(B + img_off(c / BCH, c % BCH, BRB)) = sb[i]; }
   };
   index_load(0, 0);
   __syncthreads();
@@ -284,25 +332,25 @@ k_subm_wgrad(const unsigned short* __restrict__ in, const unsigned short* __rest
     const bool have_next = blk + 1 < nblk;
     if (have_next) stage_load(b ^ 1);
     {
-      const char* A = smem + b * 2 * IMG; const char* B = A + IMG;
+      const char* A = smem + b * (AIMG + BIMG); const char* B = A + AIMG;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        bf8_t af[4], bf[4];
+        bf8_t af[TM], bf[TN];
         const int r0 = 32 * kk + 4 * g + (lq >> 2);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-          int ch = (64 * wm + 16 * mi) / 8 + ((lq & 3) >> 1);
-          af[mi] = cv_cat(cv_lds_tr(A + cv_tr_off(r0, ch) + 8 * (lq & 1)), cv_lds_tr(A + cv_tr_off(r0 + 16, ch) + 8 * (lq & 1)));
+        for (int mi = 0; mi < TM; ++mi) {
+          int ch = (16 * TM * wm + 16 * mi) / 8 + ((lq & 3) >> 1);
+          af[mi] = cv_cat(cv_lds_tr(A + img_off(r0, ch, ARB) + 8 * (lq & 1)), cv_lds_tr(A + img_off(r0 + 16, ch, ARB) + 8 * (lq & 1)));
         }
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          int ch = (64 * wn + 16 * ni) / 8 + ((lq & 3) >> 1);
-          bf[ni] = cv_cat(cv_lds_tr(B + cv_tr_off(r0, ch) + 8 * (lq & 1)), cv_lds_tr(B + cv_tr_off(r0 + 16, ch) + 8 * (lq & 1)));
+        for (int ni = 0; ni < TN; ++ni) {
+          int ch = (16 * TN * wn + 16 * ni) / 8 + ((lq & 3) >> 1);
+          bf[ni] = cv_cat(cv_lds_tr(B + img_off(r0, ch, BRB) + 8 * (lq & 1)), cv_lds_tr(B + img_off(r0 + 16, ch, BRB) + 8 * (lq & 1)));
         }
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = MFMA16(af[mi], bf[ni], acc[mi][ni]);
+          for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = MFMA16(af[mi], bf[ni], acc[mi][ni]);
       }
     }
     __syncthreads();                    // all reads of buffer b and of index slot b are done
@@ -311,14 +359,14 @@ k_subm_wgrad(const unsigned short* __restrict__ in, const unsigned short* __rest
     __syncthreads();
   }
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      int co = m0 + 64 * wm + 16 * mi + 4 * g + r;
+      int co = m0 + 16 * TM * wm + 16 * mi + 4 * g + r;
       if (co < Cout) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          int ci = n0 + 64 * wn + 16 * ni + lq;
+        for (int ni = 0; ni < TN; ++ni) {
+          int ci = n0 + 16 * TN * wn + 16 * ni + lq;
           if (ci < Cin) atomicAdd(dW + ((int64_t)co * taps + tap) * Cin + ci, acc[mi][ni][r]);
         }
       }
@@ -331,10 +379,10 @@ static int subm_gemm_launch(const unsigned short* x, const unsigned short* w, co
   // the 256 x 256 form needs enough tiles to fill 256 CUs at one workgroup each
   if (cout >= 256 && (int64_t)ss_div_up(n, 256) * ss_div_up(cout, 256) >= 256) {
     dim3 g(ss_div_up(n, 256), ss_div_up(cout, 256)), b(512);
-    SS_LAUNCH((k_subm_gemm<OutT, 4, 2, 4, 8>), g, b, 0, stream, x, w, bias, nbr, rowperm, out, n, cin, cout, taps);
+    SS_LAUNCH((k_subm_gemm<OutT, 4, 2, 4, 8, SS_CONV_DMA_BIG>), g, b, 0, stream, x, w, bias, nbr, rowperm, out, n, cin, cout, taps);
   } else {
     dim3 g(ss_div_up(n, 128), ss_div_up(cout, 128)), b(256);
-    SS_LAUNCH((k_subm_gemm<OutT, 2, 2, 4, 4>), g, b, 0, stream, x, w, bias, nbr, rowperm, out, n, cin, cout, taps);
+    SS_LAUNCH((k_subm_gemm<OutT, 2, 2, 4, 4, SS_CONV_DMA_SMALL>), g, b, 0, stream, x, w, bias, nbr, rowperm, out, n, cin, cout, taps);
   }
   return SS_OK;
 }
@@ -355,15 +403,21 @@ extern "C" int ss_subm_conv_wgrad(const void* in, const void* dout, const int32_
                                   int cout, int taps, hipStream_t stream) {
   if (n < 0 || cin <= 0 || cout <= 0 || taps <= 0 || (cin & 7) || (cout & 7) || n >= (1LL << 31)) return SS_ERR_ARG;
   if (n == 0) return SS_OK;
-  const int tm = ss_div_up(cout, 128), tn = ss_div_up(cin, 128);
   const int nblocks = ss_div_up(n, 64);
+  // the 256 x 256 form pays off only with long K loops per workgroup (its fp32-atomic epilogue is 4x larger)
+  const bool big = cout >= 256 && cin >= 256 && nblocks >= 1024;
+  const int T = big ? 256 : 128;
+  const int tm = ss_div_up(cout, T), tn = ss_div_up(cin, T);
   // taps are very unevenly populated on surfaces (about a third carry almost all pairs): size the K split for the
-  // busy ones so that ~2k workgroups of useful work exist
-  int splits = 6144 / (tm * tn * taps);
+  // busy ones so that enough workgroups of useful work exist
+  int splits = (big ? 3072 : 6144) / (tm * tn * taps);
   if (splits > nblocks / 8) splits = nblocks / 8;
   if (splits < 1) splits = 1;
-  dim3 g(tm * tn, taps, splits), b(CV_THREADS);
-  SS_LAUNCH(k_subm_wgrad, g, b, 0, stream, (const unsigned short*)in, (const unsigned short*)dout, nbr, rowperm, blk_count,
-            blk_list, dweight, (int)n, cin, cout, taps, tn, nblocks);
+  dim3 g(tm * tn, taps, splits);
+  const unsigned short* x = (const unsigned short*)in; const unsigned short* go = (const unsigned short*)dout;
+  if (big)
+    SS_LAUNCH((k_subm_wgrad<2, 4, 8, 4>), g, dim3(512), 0, stream, x, go, nbr, rowperm, blk_count, blk_list, dweight, (int)n, cin, cout, taps, tn, nblocks);
+  else
+    SS_LAUNCH((k_subm_wgrad<2, 2, 4, 4>), g, dim3(256), 0, stream, x, go, nbr, rowperm, blk_count, blk_list, dweight, (int)n, cin, cout, taps, tn, nblocks);
   return SS_OK;
 }
