@@ -26,6 +26,9 @@ typedef __attribute__((address_space(3))) s4_t lds_s4_t;
 #define CV_BM 128
 #define CV_BN 128
 #define CV_BK 64
+#ifndef SS_CONV_BIG_MIN_TILES
+#define SS_CONV_BIG_MIN_TILES 128
+#endif
 #ifndef SS_CONV_DMA_SMALL
 #define SS_CONV_DMA_SMALL false
 #endif
@@ -377,7 +380,7 @@ template <typename OutT>
 static int subm_gemm_launch(const unsigned short* x, const unsigned short* w, const float* bias, const int32_t* nbr,
                             const int32_t* rowperm, OutT* out, int n, int cin, int cout, int taps, hipStream_t stream) {
   // the 256 x 256 form needs enough tiles to fill 256 CUs at one workgroup each
-  if (cout >= 256 && (int64_t)ss_div_up(n, 256) * ss_div_up(cout, 256) >= 256) {
+  if (cout >= 256 && (int64_t)ss_div_up(n, 256) * ss_div_up(cout, 256) >= SS_CONV_BIG_MIN_TILES) {
     dim3 g(ss_div_up(n, 256), ss_div_up(cout, 256)), b(512);
     SS_LAUNCH((k_subm_gemm<OutT, 4, 2, 4, 8, SS_CONV_DMA_BIG>), g, b, 0, stream, x, w, bias, nbr, rowperm, out, n, cin, cout, taps);
   } else {

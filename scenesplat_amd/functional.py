@@ -123,15 +123,15 @@ class _SubMConv3d(torch.autograd.Function):
             dw = dw.permute(1, 0, 2).reshape(weight.shape).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = g.sum(0).to(weight.dtype)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class _SubMConv3dFused(torch.autograd.Function):
     """bf16 MFMA implicit-GEMM path (csrc/subm_conv.hip): one launch each for forward, dgrad
-    (same kernel, tap-mirrored transposed weights) and wgrad.  Needs unique voxels."""
+    (same kernel, tap-mirrored transposed weights) and wgrad; duplicate voxels handled exactly."""
 
     @staticmethod
-    def forward(ctx, feat, weight, bias, nbr, rowperm, blocks_fn):
+    def forward(ctx, feat, weight, bias, nbr, rowperm, blocks_fn, has_dup):
         taps, n = nbr.shape
         cout, cin = weight.shape[0], weight.shape[-1]
         pad = (-cin) % 8
@@ -143,7 +143,7 @@ class _SubMConv3dFused(torch.autograd.Function):
         out = nv.subm_conv_fwd(x, w, None if bias is None else bias.float().contiguous(), nbr, rowperm)
         ctx.save_for_backward(x, w, nbr, rowperm)
         ctx.meta = (feat.dtype, weight.dtype, weight.shape, cin, bias is not None)
-        ctx.blocks_fn = blocks_fn
+        ctx.blocks_fn, ctx.has_dup = blocks_fn, has_dup
         return out
 
     @staticmethod
@@ -154,20 +154,30 @@ class _SubMConv3dFused(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wt = w.flip(1).permute(2, 1, 0).contiguous()          # [ci][t'][co] = w[co][T-1-t'][ci]
-            dx = nv.subm_conv_fwd(g, wt, None, nbr, rowperm)[:, :cin].to(in_dtype)
+            if not ctx.has_dup:
+                dx = nv.subm_conv_fwd(g, wt, None, nbr, rowperm)[:, :cin].to(in_dtype)
+            else:
+                # duplicate voxels (Mix3D batches): every site at a voxel reads the voxel's WINNER row, so the
+                # adjoint first folds the gradients of all duplicates onto their winner, runs the symmetric
+                # gather on that, and leaves non-winner rows (which nobody reads) with zero gradient
+                winner = nbr[nbr.shape[0] // 2].long()
+                is_w = winner == torch.arange(winner.numel(), device=winner.device)
+                gsum = torch.zeros(g.shape, dtype=torch.float32, device=g.device).index_add_(0, winner, g.float())
+                dx = nv.subm_conv_fwd(gsum.to(torch.bfloat16), wt, None, nbr, rowperm)[:, :cin]
+                dx = (dx * is_w.unsqueeze(1)).to(in_dtype)
         if ctx.needs_input_grad[1]:
             blocks = ctx.blocks_fn() if ctx.blocks_fn is not None else nv.subm_block_lists(nbr, rowperm)
             dw = nv.subm_conv_wgrad(x, g, nbr, rowperm, blocks)[:, :, :cin].reshape(w_shape).to(w_dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = g.sum(0, dtype=torch.float32).to(w_dtype)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 def subm_conv3d(feat, weight, bias, nbr, has_dup=False, compute_dtype=torch.float32, rowperm=None, blocks_fn=None):
     """weight (Cout, k, k, k, Cin) as in the reference checkpoints; nbr (k^3, n) tap-major.
     bf16 compute on unique voxels -> fused MFMA kernels; otherwise per-tap gather + GEMM."""
-    if compute_dtype == torch.bfloat16 and not has_dup and weight.shape[0] % 8 == 0:
-        return _SubMConv3dFused.apply(feat, weight, bias, nbr, rowperm, blocks_fn)
+    if compute_dtype == torch.bfloat16 and weight.shape[0] % 8 == 0:
+        return _SubMConv3dFused.apply(feat, weight, bias, nbr, rowperm, blocks_fn, has_dup)
     return _SubMConv3d.apply(feat, weight, bias, nbr, has_dup, compute_dtype)
 
 

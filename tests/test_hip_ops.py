@@ -104,18 +104,22 @@ def test_subm_conv_against_oracle(k, cin, cout, dup):
     assert torch.allclose(bg.grad.cpu(), bo.grad, atol=1e-3, rtol=1e-4)
 
 
-@pytest.mark.parametrize("k,cin,cout", [(3, 32, 32), (3, 96, 160), (5, 11, 32), (3, 256, 256), (3, 64, 8)])
-def test_subm_conv_fused_mfma_against_oracle(k, cin, cout):
+@pytest.mark.parametrize("k,cin,cout,dup", [(3, 32, 32, False), (3, 96, 160, False), (5, 11, 32, False), (3, 256, 256, False),
+                                             (3, 64, 8, False), (3, 32, 48, True), (5, 16, 16, True)])
+def test_subm_conv_fused_mfma_against_oracle(k, cin, cout, dup):
     """bf16 MFMA implicit-GEMM conv (fwd, dgrad, wgrad) vs the fp32 oracle on bf16-rounded operands."""
     from scenesplat_amd import functional as SF
     from scenesplat_amd.plan import build_plan
     g = torch.Generator().manual_seed(k * 1000 + cin + cout)
-    gc = torch.unique(torch.randint(0, 14, (2600, 3), generator=g), dim=0)
+    gc = torch.randint(0, 14, (2600, 3), generator=g)
+    if not dup:
+        gc = torch.unique(gc, dim=0)         # dup=True keeps the repeated voxels (Mix3D-style batches)
     gc = gc[torch.randperm(len(gc), generator=g)]
     n = len(gc)
     offs = torch.tensor([n // 3, n])
     plan = build_plan(gc.cuda(), offs.cuda(), ORD, ())
     lv = plan.levels[0]
+    assert lv.has_duplicates == dup
     batch = np.repeat([0, 1], [n // 3, n - n // 3])
     nbr = oops.neighbor_table(gc.numpy(), batch, k)
     rb = lambda t: t.to(torch.bfloat16).float()
@@ -125,7 +129,7 @@ def test_subm_conv_fused_mfma_against_oracle(k, cin, cout):
     yo = oops.subm_conv3d(xo, wo, bo, nbr)
     (yo * cot).sum().backward()
     xg, wg, bg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
-    y = SF.subm_conv3d(xg, wg, bg, lv.neighbors(k), False, torch.bfloat16, lv.conv_rowperm())
+    y = SF.subm_conv3d(xg, wg, bg, lv.neighbors(k), lv.has_duplicates, torch.bfloat16, lv.conv_rowperm())
     assert y.dtype == torch.bfloat16
     (y.float() * cot.cuda()).sum().backward()
     def rel(a, r): return ((a.float().cpu() - r).norm() / r.norm()).item()
