@@ -111,8 +111,9 @@ __device__ __forceinline__ void tile_load(uint4 (&reg)[NLD], const unsigned shor
 // =====================================================================================
 // forward
 // =====================================================================================
+// d <= 32 fits 128 VGPRs (4 waves/SIMD, +5 %); forcing d = 48 under 128 spills and loses 7 %, it runs at 144 / 3 waves
 template <int D>
-__global__ void __launch_bounds__(FA_THREADS)
+__global__ void __launch_bounds__(FA_THREADS, (D <= 32 ? 4 : 1))
 k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restrict__ gidx,
                 const int32_t* __restrict__ sidx, const int32_t* __restrict__ win_start,
                 unsigned short* __restrict__ out, float* __restrict__ lse, int C, int H, float scale, int qchunks) {
