@@ -173,6 +173,9 @@ int ss_rpe_dot_prod_fwd(int n, int m, int h, int hdim, const float* q, const int
 int ss_rpe_dot_prod_bwd(int n, int m, int h, int hdim, const float* grad_out, const float* q, const int32_t* index, const float* table, const int32_t* rel_idx, float* grad_q, float* grad_table, ss_stream_t stream);
 int ss_rpe_attn_step2_fwd(int n, int m, int h, int hdim, const float* attn, const float* v, const int32_t* index0, const int32_t* index1, const float* table, const int32_t* rel_idx, float* output, ss_stream_t stream);
 int ss_rpe_attn_step2_bwd(int n, int m, int h, int hdim, const float* grad_out, const int32_t* index0, const int32_t* index1, const float* attn, const float* v, const float* table, const int32_t* rel_idx, float* grad_attn, float* grad_v, float* grad_table, ss_stream_t stream);
+/* neighbour majority vote of the zero-shot evaluator (pointcept/utils/misc.py:17-51): ties -> smallest label, k <= 64 */
+int ss_majority_vote(const int32_t* nn_idx, const int32_t* labels, int64_t m, int k, int ignore_label, int num_classes,
+                     int32_t* out, ss_stream_t stream);
 /* libs/pointgroup_ops/src/bfs_cluster.cpp:140-145.  total (1) device int = number of pairs found */
 int ss_ballquery_batch_p(int n, int mean_active, float radius, const float* xyz, const int32_t* batch_idxs, const int32_t* batch_offsets, int32_t* idx, int32_t* start_len, int32_t* total, ss_stream_t stream);
 /* HOST pointers (CPU BFS, as the reference) */

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "ss_rpe_dot_prod_bwd": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "ss_rpe_attn_step2_fwd": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "ss_rpe_attn_step2_bwd": (c_i, [c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "ss_majority_vote": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_p]),
     "ss_ballquery_batch_p": (c_i, [c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "ss_bfs_cluster": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_i64, c_p, c_i64, c_p, c_p]),
 }

@@ -536,3 +536,36 @@ extern "C" int ss_bfs_cluster(const int32_t* semantic_label, const int32_t* ball
   }
   return SS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// neighbour majority vote (pointcept/utils/misc.py:17-51, used by engines/hooks/evaluator.py:697-739):
+// out[i] = most frequent valid label among labels[nn_idx[i][0..k)], ties -> smallest label,
+// ignore_label when no neighbour carries a valid label.  k <= 64.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_majority_vote(const int32_t* __restrict__ nn_idx, const int32_t* __restrict__ labels, int64_t m, int k,
+                                int ignore_label, int num_classes, int32_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  int lab[64];
+  for (int j = 0; j < k; ++j) {
+    int id = nn_idx[i * k + j];
+    int l = id >= 0 ? labels[id] : ignore_label;
+    lab[j] = (l != ignore_label && l >= 0 && l < num_classes) ? l : -1;
+  }
+  int best = ignore_label, best_cnt = 0;
+  for (int j = 0; j < k; ++j) {
+    int l = lab[j];
+    if (l < 0) continue;
+    int c = 0;
+    for (int q = 0; q < k; ++q) c += (lab[q] == l);
+    if (c > best_cnt || (c == best_cnt && l < best)) { best_cnt = c; best = l; }
+  }
+  out[i] = best;
+}
+extern "C" int ss_majority_vote(const int32_t* nn_idx, const int32_t* labels, int64_t m, int k, int ignore_label,
+                                int num_classes, int32_t* out, hipStream_t stream) {
+  if (m < 0 || k < 1 || k > 64 || num_classes < 1) return SS_ERR_ARG;
+  if (m == 0) return SS_OK;
+  SS_LAUNCH(k_majority_vote, dim3(ss_div_up(m, 128)), dim3(128), 0, stream, nn_idx, labels, m, k, ignore_label, num_classes, out);
+  return SS_OK;
+}

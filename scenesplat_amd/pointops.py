@@ -389,3 +389,29 @@ def bfs_cluster(semantic_label, ball_query_idxs, start_len, threshold):
     if rc != 0:
         raise NativeError(f"ss_bfs_cluster failed: status {rc}")
     return cidx[:npts.value].clone(), coff[:nc.value + 1].clone()
+
+
+# ---- evaluator helpers -----------------------------------------------------------------
+def majority_vote(nn_idx, labels, ignore_label, num_classes):
+    """out[i] = most frequent valid label among labels[nn_idx[i]] (ties -> smallest label)."""
+    nn_idx, labels = _i(nn_idx, "nn_idx"), _i(labels, "labels")
+    m, k = nn_idx.shape
+    out = torch.empty(m, dtype=torch.int32, device=nn_idx.device)
+    check(nv.lib().ss_majority_vote(_p(nn_idx), _p(labels), m, k, int(ignore_label), int(num_classes), _p(out), _s()),
+          "ss_majority_vote")
+    return out
+
+
+def neighbor_voting(coords, initial_labels, valid_mask, vote_k, ignore_label, num_classes, query_coords=None):
+    """GPU form of LangPretrainZeroShotSemSegEval._neighbor_voting (engines/hooks/evaluator.py:697-739, top-1):
+    kNN (k = vote_k) among the valid Gaussians + majority vote, instead of CPU cKDTree + numba."""
+    valid = valid_mask.bool()
+    vc = coords[valid].float().contiguous()
+    q = (coords if query_coords is None else query_coords).float().contiguous()
+    if vc.shape[0] == 0:
+        return torch.full((q.shape[0],), ignore_label, dtype=torch.int32, device=coords.device)
+    k = min(int(vote_k), vc.shape[0])
+    off = torch.tensor([vc.shape[0]], dtype=torch.int32, device=coords.device)
+    noff = torch.tensor([q.shape[0]], dtype=torch.int32, device=coords.device)
+    idx, _ = knn_query(k, vc, off, q, noff)
+    return majority_vote(idx, initial_labels[valid], ignore_label, num_classes)

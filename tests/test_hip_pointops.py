@@ -171,3 +171,43 @@ def test_pointgroup_ballquery_and_bfs_cluster():
     cidx, coff = po.bfs_cluster(torch.as_tensor(labels), idx.cpu(), start_len.cpu(), 10)
     ri, ro = opo.bfs_cluster(labels, ridx, rsl, 10)
     assert np.array_equal(cidx.numpy(), ri) and np.array_equal(coff.numpy(), ro)
+
+
+def test_neighbor_voting_and_majority_vote():
+    from scenesplat_amd import pointops as po
+    g = np.random.default_rng(11)
+    n, k, C = 3000, 25, 20
+    xyz = g.random((n, 3), dtype=np.float32)
+    lab = g.integers(0, C, n).astype(np.int32)
+    lab[g.random(n) < 0.1] = -1
+    valid = g.random(n) < 0.8
+    out = po.neighbor_voting(cu(xyz), cu(lab), cu(valid), k, -1, C).cpu().numpy()
+    vi = np.nonzero(valid)[0]
+    d = ((xyz[:, None, :] - xyz[None, vi, :]) ** 2).sum(-1)
+    nn = np.argsort(d, 1, kind="stable")[:, :k]
+    nl = lab[vi][nn]
+    ref = np.full(n, -1, np.int32)
+    for i in range(n):          # pointcept/utils/misc.py:33-48
+        cnt = np.bincount(nl[i][nl[i] >= 0], minlength=C)
+        if cnt.max() > 0:
+            ref[i] = int(np.argmax(cnt))
+    assert (out == ref).mean() > 0.999        # fp distance ties at the k-th neighbour may differ
+
+
+def test_gpu_grid_sample_train_semantics():
+    from scenesplat_amd.gpu_transforms import grid_sample_train
+    g = torch.Generator().manual_seed(0)
+    coord = torch.rand(50000, 3, generator=g) * torch.tensor([4.0, 3.0, 1.0])
+    gs = 0.05
+    res = grid_sample_train(coord.cuda(), gs, return_inverse=True)
+    gc_all = np.floor(coord.numpy() / gs).astype(np.int64)
+    gc_all -= gc_all.min(0)
+    uniq = np.unique(gc_all, axis=0)
+    sel = res["idx_unique"].cpu().numpy()
+    assert len(sel) == len(uniq)                                            # one point per occupied voxel
+    assert np.array_equal(np.unique(gc_all[sel], axis=0), uniq)             # every voxel represented exactly once
+    assert np.array_equal(res["grid_coord"].cpu().numpy(), gc_all[sel])
+    inv = res["inverse"].cpu().numpy()
+    assert np.array_equal(gc_all[sel][inv], gc_all)                         # inverse maps each point to its voxel's row
+    res2 = grid_sample_train(coord.cuda(), gs)
+    assert not np.array_equal(sel, res2["idx_unique"].cpu().numpy())         # random representative
