@@ -91,6 +91,10 @@ int ss_subm_rulebook(const int32_t* grid_coord, const int32_t* batch, int64_t n,
  * transposed weight (cin,taps,cout). */
 int ss_subm_conv_fwd(const void* in, const void* weight, const float* bias, const int32_t* nbr, const int32_t* rowperm,
                      void* out, int64_t n, int cin, int cout, int taps, int out_dtype, ss_stream_t stream);
+/* small levels: split-K over tap ranges; acc32 (n,cout) f32 zeroed by the caller, receives out (+bias) */
+int ss_subm_conv_splits(int64_t n, int cout, int taps);
+int ss_subm_conv_fwd_splitk(const void* in, const void* weight, const float* bias, const int32_t* nbr, const int32_t* rowperm,
+                            float* acc32, int64_t n, int cin, int cout, int taps, int splits, ss_stream_t stream);
 /* per tap, the 64-site blocks (in rowperm order) that hold at least one pair: blk_count (taps), blk_list (taps, ceil(n/64)) */
 int ss_subm_block_lists(const int32_t* nbr, const int32_t* rowperm, int64_t n, int taps, int32_t* blk_count,
                         int32_t* blk_list, ss_stream_t stream);

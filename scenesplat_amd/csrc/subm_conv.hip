@@ -75,7 +75,9 @@ template <typename OutT, int WM, int WN, int TM, int TN, bool DMA>
 __global__ void __launch_bounds__(64 * WM * WN)
 k_subm_gemm(const unsigned short* __restrict__ in, const unsigned short* __restrict__ W, const float* __restrict__ bias,
             const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowperm, OutT* __restrict__ out, int n,
-            int Cin, int Cout, int taps) {
+            int Cin, int Cout, int taps, float* __restrict__ acc32) {
+  // gridDim.z > 1: split-K over tap ranges for small levels (a 1,600-site level has 26 tiles for 256 CUs and a
+  // serial 27-tap loop); partial sums go to the zeroed fp32 buffer acc32 with atomics, the caller converts
   constexpr int THREADS = 64 * WM * WN, BM = 16 * TM * WM, BN = 16 * TN * WN;
   constexpr int AIMG = BM * CV_BK * 2, BIMG = BN * CV_BK * 2;
   constexpr int NLA = (BM * 8) / THREADS, NLB = (BN * 8) / THREADS;      // 16-byte chunks per thread per K-step
@@ -142,8 +144,10 @@ k_subm_gemm(const unsigned short* __restrict__ in, const unsigned short* __restr
 #pragma unroll
     for (int i = 0; i < NLB; ++i) { int c = i * THREADS + tid; *reinterpret_cast<uint4*>(B + cv_row_off(c >> 3, c & 7)) = sb[i]; }
   };
-  for (int tg = 0; tg < taps; tg += CV_TG) {
-    const int nt = min(CV_TG, taps - tg);
+  const int taps_per_z = (taps + gridDim.z - 1) / gridDim.z;
+  const int tap_beg = blockIdx.z * taps_per_z, tap_end = min(taps, tap_beg + taps_per_z);
+  for (int tg = tap_beg; tg < tap_end; tg += CV_TG) {
+    const int nt = min(CV_TG, tap_end - tg);
     __syncthreads();                     // previous group's LDS reads are done
     if (tid == 0) mask_s = 0u;
     __syncthreads();
@@ -207,7 +211,11 @@ k_subm_gemm(const unsigned short* __restrict__ in, const unsigned short* __restr
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni) {
       const int col = n0 + 16 * TN * wn + 16 * ni + 4 * g;
-      if (col + 3 < Cout && (Cout & 3) == 0) {
+      if (acc32) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col + r < Cout) atomicAdd(acc32 + (int64_t)row * Cout + col + r, acc[mi][ni][r] + ((bias && blockIdx.z == 0) ? bias[col + r] : 0.f));
+      } else if (col + 3 < Cout && (Cout & 3) == 0) {
         float4 v = make_float4(acc[mi][ni][0], acc[mi][ni][1], acc[mi][ni][2], acc[mi][ni][3]);
         if (bias) { float4 bv = *reinterpret_cast<const float4*>(bias + col); v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
         OutT* op = out + (int64_t)row * Cout + col;
@@ -378,14 +386,20 @@ k_subm_wgrad(const unsigned short* __restrict__ in, const unsigned short* __rest
 
 template <typename OutT>
 static int subm_gemm_launch(const unsigned short* x, const unsigned short* w, const float* bias, const int32_t* nbr,
-                            const int32_t* rowperm, OutT* out, int n, int cin, int cout, int taps, hipStream_t stream) {
+                            const int32_t* rowperm, OutT* out, int n, int cin, int cout, int taps, hipStream_t stream,
+                            float* acc32 = nullptr, int splits = 1) {
+  if (acc32) {
+    dim3 g(ss_div_up(n, 128), ss_div_up(cout, 128), splits), b(256);
+    SS_LAUNCH((k_subm_gemm<OutT, 2, 2, 4, 4, SS_CONV_DMA_SMALL>), g, b, 0, stream, x, w, bias, nbr, rowperm, out, n, cin, cout, taps, acc32);
+    return SS_OK;
+  }
   // the 256 x 256 form needs enough tiles to fill 256 CUs at one workgroup each
   if (cout >= 256 && (int64_t)ss_div_up(n, 256) * ss_div_up(cout, 256) >= SS_CONV_BIG_MIN_TILES) {
     dim3 g(ss_div_up(n, 256), ss_div_up(cout, 256)), b(512);
-    SS_LAUNCH((k_subm_gemm<OutT, 4, 2, 4, 8, SS_CONV_DMA_BIG>), g, b, 0, stream, x, w, bias, nbr, rowperm, out, n, cin, cout, taps);
+    SS_LAUNCH((k_subm_gemm<OutT, 4, 2, 4, 8, SS_CONV_DMA_BIG>), g, b, 0, stream, x, w, bias, nbr, rowperm, out, n, cin, cout, taps, (float*)nullptr);
   } else {
     dim3 g(ss_div_up(n, 128), ss_div_up(cout, 128)), b(256);
-    SS_LAUNCH((k_subm_gemm<OutT, 2, 2, 4, 4, SS_CONV_DMA_SMALL>), g, b, 0, stream, x, w, bias, nbr, rowperm, out, n, cin, cout, taps);
+    SS_LAUNCH((k_subm_gemm<OutT, 2, 2, 4, 4, SS_CONV_DMA_SMALL>), g, b, 0, stream, x, w, bias, nbr, rowperm, out, n, cin, cout, taps, (float*)nullptr);
   }
   return SS_OK;
 }
@@ -399,6 +413,25 @@ extern "C" int ss_subm_conv_fwd(const void* in, const void* weight, const float*
   if (out_dtype == SS_BF16) return subm_gemm_launch<unsigned short>(x, w, bias, nbr, rowperm, (unsigned short*)out, (int)n, cin, cout, taps, stream);
   if (out_dtype == SS_F32) return subm_gemm_launch<float>(x, w, bias, nbr, rowperm, (float*)out, (int)n, cin, cout, taps, stream);
   return SS_ERR_ARG;
+}
+
+// split-K form for small levels: acc32 (n, cout) f32 must be zero on entry and receives out (+ bias); `splits`
+// tap ranges run as separate workgroups.  ss_subm_conv_splits() is the recommended count (1 = use ss_subm_conv_fwd).
+extern "C" int ss_subm_conv_splits(int64_t n, int cout, int taps) {
+  int64_t tiles = (int64_t)ss_div_up(n, 128) * ss_div_up(cout, 128);
+  if (tiles >= 192) return 1;
+  int z = (int)((256 + tiles - 1) / tiles);
+  if (z > taps) z = taps;
+  if (z > 9) z = 9;
+  return z < 2 ? 1 : z;
+}
+extern "C" int ss_subm_conv_fwd_splitk(const void* in, const void* weight, const float* bias, const int32_t* nbr,
+                                       const int32_t* rowperm, float* acc32, int64_t n, int cin, int cout, int taps,
+                                       int splits, hipStream_t stream) {
+  if (n < 0 || cin <= 0 || cout <= 0 || taps <= 0 || (cin & 7) || n >= (1LL << 31) || splits < 1 || !acc32) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  return subm_gemm_launch<float>((const unsigned short*)in, (const unsigned short*)weight, bias, nbr, rowperm, acc32,
+                                 (int)n, cin, cout, taps, stream, acc32, splits);
 }
 
 extern "C" int ss_subm_conv_wgrad(const void* in, const void* dout, const int32_t* nbr, const int32_t* rowperm,

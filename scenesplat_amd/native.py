@@ -164,6 +164,12 @@ def subm_conv_fwd(x, w, bias, nbr, rowperm, out_dtype=torch.bfloat16):
         _req(bias, torch.float32, "bias", (cout,))
     if rowperm is not None:
         _req(rowperm, torch.int32, "rowperm", (n,))
+    splits = lib().ss_subm_conv_splits(n, cout, taps)
+    if splits > 1:      # small level: tap ranges in parallel, fp32 atomics, one conversion pass
+        acc = torch.zeros((n, cout), dtype=torch.float32, device=x.device)
+        check(lib().ss_subm_conv_fwd_splitk(_p(x), _p(w), _p(bias), _p(nbr), _p(rowperm), _p(acc), n, cin, cout, taps, splits,
+                                            _stream()), "ss_subm_conv_fwd_splitk")
+        return acc if out_dtype == torch.float32 else acc.to(out_dtype)
     out = torch.empty((n, cout), dtype=out_dtype, device=x.device)
     check(lib().ss_subm_conv_fwd(_p(x), _p(w), _p(bias), _p(nbr), _p(rowperm), _p(out), n, cin, cout, taps,
                                  dtype_code(out), _stream()), "ss_subm_conv_fwd")
