@@ -91,6 +91,15 @@ int ss_subm_rulebook(const int32_t* grid_coord, const int32_t* batch, int64_t n,
  * transposed weight (cin,taps,cout). */
 int ss_subm_conv_fwd(const void* in, const void* weight, const float* bias, const int32_t* nbr, const int32_t* rowperm,
                      void* out, int64_t n, int cin, int cout, int taps, int out_dtype, ss_stream_t stream);
+/* 256 x 256 LDS-DMA pipeline GEMM (csrc/gemm8.hip).  ss_gemm8_ok: shapes it accepts (k % 64 == 0, k <= 4096, n % 4 == 0,
+ * taps <= 27).  ss_subm_conv_fwd_pipe: same contract as ss_subm_conv_fwd (which dispatches to it for wide, large levels).
+ * ss_linear_fwd: out (m,n) = x (m,k) bf16 @ weight (n,k)^T bf16 + bias (n) f32 or NULL  -- torch.nn.functional.linear as
+ * PTv3 uses it (ptv3:131-133 qkv/proj, ptv3:224-228 MLP). */
+int ss_gemm8_ok(int64_t m, int k, int n, int taps);
+int ss_subm_conv_fwd_pipe(const void* in, const void* weight, const float* bias, const int32_t* nbr, const int32_t* rowperm,
+                          void* out, int64_t n, int cin, int cout, int taps, int out_dtype, ss_stream_t stream);
+int ss_linear_fwd(const void* x, const void* weight, const float* bias, void* out, int64_t m, int k, int n, int out_dtype,
+                  ss_stream_t stream);
 /* small levels: split-K over tap ranges; acc32 (n,cout) f32 zeroed by the caller, receives out (+bias) */
 int ss_subm_conv_splits(int64_t n, int cout, int taps);
 int ss_subm_conv_fwd_splitk(const void* in, const void* weight, const float* bias, const int32_t* nbr, const int32_t* rowperm,

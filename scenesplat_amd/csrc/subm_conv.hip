@@ -15,6 +15,7 @@
 // MFMA: v_mfma_f32_16x16x32_bf16, 128x128 workgroup tile, 4 waves (2x2) of 64x64, BK = 64.
 #include "common.h"
 #include "../../include/scenesplat_hip.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
 typedef __attribute__((ext_vector_type(4))) short s4_t;
@@ -404,11 +405,21 @@ static int subm_gemm_launch(const unsigned short* x, const unsigned short* w, co
   return SS_OK;
 }
 
+// SS_CONV_PIPE=0/1 overrides the choice between k_subm_gemm and the LDS-DMA pipeline kernel (gemm8.hip)
+static int conv_pipe_mode() {
+  static int mode = -2;
+  if (mode == -2) { const char* e = getenv("SS_CONV_PIPE"); mode = e ? atoi(e) : -1; }
+  return mode;
+}
+
 extern "C" int ss_subm_conv_fwd(const void* in, const void* weight, const float* bias, const int32_t* nbr,
                                 const int32_t* rowperm, void* out, int64_t n, int cin, int cout, int taps, int out_dtype,
                                 hipStream_t stream) {
   if (n < 0 || cin <= 0 || cout <= 0 || taps <= 0 || (cin & 7) || n >= (1LL << 31)) return SS_ERR_ARG;
   if (n == 0) return SS_OK;
+  if (ss_gemm8_ok(n, cin, cout, taps) && conv_pipe_mode() != 0 &&
+      (conv_pipe_mode() == 1 || (cout >= 256 && (int64_t)ss_div_up(n, 256) * ss_div_up(cout, 256) >= SS_CONV_BIG_MIN_TILES)))
+    return ss_subm_conv_fwd_pipe(in, weight, bias, nbr, rowperm, out, n, cin, cout, taps, out_dtype, stream);
   const unsigned short* x = (const unsigned short*)in; const unsigned short* w = (const unsigned short*)weight;
   if (out_dtype == SS_BF16) return subm_gemm_launch<unsigned short>(x, w, bias, nbr, rowperm, (unsigned short*)out, (int)n, cin, cout, taps, stream);
   if (out_dtype == SS_F32) return subm_gemm_launch<float>(x, w, bias, nbr, rowperm, (float*)out, (int)n, cin, cout, taps, stream);

@@ -176,6 +176,25 @@ def subm_conv_fwd(x, w, bias, nbr, rowperm, out_dtype=torch.bfloat16):
     return out
 
 
+def subm_conv_fwd_pipe(x, w, bias, nbr, rowperm, out_dtype=torch.bfloat16):
+    """The LDS-DMA pipeline kernel directly (tests / benches); subm_conv_fwd dispatches to it for wide, large levels."""
+    n, cin = x.shape
+    cout, taps = w.shape[0], w.shape[1]
+    out = torch.empty((n, cout), dtype=out_dtype, device=x.device)
+    check(lib().ss_subm_conv_fwd_pipe(_p(x), _p(w), _p(bias), _p(nbr), _p(rowperm), _p(out), n, cin, cout, taps,
+                                      dtype_code(out), _stream()), "ss_subm_conv_fwd_pipe")
+    return out
+
+
+def linear_fwd(x, w, bias=None, out_dtype=torch.bfloat16):
+    """out = x @ w.T + bias on the pipeline GEMM.  x (m,k) bf16, w (n,k) bf16, bias (n) f32 or None."""
+    m, k = x.shape
+    n = w.shape[0]
+    out = torch.empty((m, n), dtype=out_dtype, device=x.device)
+    check(lib().ss_linear_fwd(_p(x), _p(w), _p(bias), _p(out), m, k, n, dtype_code(out), _stream()), "ss_linear_fwd")
+    return out
+
+
 def subm_block_lists(nbr, rowperm):
     """Per tap the compacted list of 64-site blocks with at least one pair: (count (taps), list (taps, nblocks))."""
     taps, n = nbr.shape

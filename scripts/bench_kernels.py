@@ -45,8 +45,42 @@ def main():
             blocks = lv.conv_blocks(3)
             tw = ev(lambda: nv.subm_conv_wgrad(x, gout, nbr, perm, blocks), 5, 2)
             fl = 2.0 * n * act * C * C
+            if nv.lib().ss_gemm8_ok(n, C, C, 27):
+                ref = nv.subm_conv_fwd(x, w, None, nbr, perm).float()
+                got = nv.subm_conv_fwd_pipe(x, w, None, nbr, perm).float()
+                err = (got - ref).abs().max().item() / ref.abs().max().item()
+                tp = ev(lambda: nv.subm_conv_fwd_pipe(x, w, None, nbr, perm), 5, 2)
+                print(f"   pipe kernel: fwd {tp:.3f} ms ({fl/tp/1e9:.0f} TF/s)  rel err vs dispatch {err:.2e}", flush=True)
             print(f"conv L{li} n={n} C={C} taps/site={act:.2f}: fwd {tf:.3f} ms ({fl/tf/1e9:.0f} TF/s)  wgrad {tw:.3f} ms ({fl/tw/1e9:.0f} TF/s)", flush=True)
 
 
+def gemm():
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for (m, k, n) in [(102400, 768, 2304), (102400, 768, 768), (102400, 768, 3072), (102400, 3072, 768),
+                      (25600, 512, 1536), (25600, 512, 2048), (25600, 2048, 512), (6400, 256, 1024), (102400, 256, 768)]:
+        x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+        b = torch.randn(n, device="cuda", generator=g)
+        bb = b.to(torch.bfloat16)
+        ref = torch.nn.functional.linear(x, w, bb).float()
+        got = nv.linear_fwd(x, w, b).float()
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        t0 = ev(lambda: torch.nn.functional.linear(x, w, bb), 10, 3)
+        t1 = ev(lambda: nv.linear_fwd(x, w, b), 10, 3)
+        dy = torch.randn(m, n, device="cuda", generator=g).to(torch.bfloat16)
+        wt = w.t().contiguous()
+        t2 = ev(lambda: dy @ w, 10, 3)                       # dgrad, NN
+        t3 = ev(lambda: nv.linear_fwd(dy, wt), 10, 3)        # dgrad on the pipe kernel with W^T
+        t4 = ev(lambda: dy.t() @ x, 10, 3)                   # wgrad, TN
+        fl = 2.0 * m * k * n
+        print(f"   dgrad hipBLASLt {t2:.3f} ms ({fl/t2/1e9:.0f} TF/s) pipe(W^T) {t3:.3f} ms ({fl/t3/1e9:.0f} TF/s) | wgrad hipBLASLt {t4:.3f} ms ({fl/t4/1e9:.0f} TF/s)", flush=True)
+        print(f"gemm m={m} k={k} n={n}: hipBLASLt {t0:.3f} ms ({fl/t0/1e9:.0f} TF/s)  pipe {t1:.3f} ms ({fl/t1/1e9:.0f} TF/s)  rel err {err:.2e}", flush=True)
+
+
 if __name__ == "__main__":
+    if "gemm" in sys.argv[1:]:
+        gemm()
+        sys.argv = [a for a in sys.argv if a != "gemm"]
+        if len(sys.argv) == 1:
+            sys.exit(0)
     main()

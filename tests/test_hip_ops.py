@@ -139,6 +139,62 @@ def test_subm_conv_fused_mfma_against_oracle(k, cin, cout, dup):
     assert rel(bg.grad, bo.grad) < 2e-3
 
 
+@pytest.mark.parametrize("k,cin,cout,dup,f32out", [(3, 64, 256, False, False), (3, 128, 72, False, True), (5, 64, 48, False, False),
+                                                    (3, 192, 260, True, False)])
+def test_subm_conv_pipeline_kernel_against_oracle(k, cin, cout, dup, f32out):
+    """The 256x256 LDS-DMA pipeline kernel (gemm8.hip, GATHER form) called directly: ragged site and channel tails,
+    k=5 needs taps <= 27 so it must be refused there."""
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.plan import build_plan
+    g = torch.Generator().manual_seed(k * 77 + cin + cout)
+    gc = torch.randint(0, 14, (2600, 3), generator=g)
+    if not dup:
+        gc = torch.unique(gc, dim=0)
+    gc = gc[torch.randperm(len(gc), generator=g)]
+    n = len(gc)
+    offs = torch.tensor([n // 3, n])
+    plan = build_plan(gc.cuda(), offs.cuda(), ORD, ())
+    lv = plan.levels[0]
+    batch = np.repeat([0, 1], [n // 3, n - n // 3])
+    rb = lambda t: t.to(torch.bfloat16).float()
+    x = rb(torch.randn(n, cin, generator=g)); w = rb(torch.randn(cout, k, k, k, cin, generator=g) * 0.2)
+    b = torch.randn(cout, generator=g)
+    wk = w.reshape(cout, k ** 3, cin).to(torch.bfloat16).cuda()
+    if k == 5:
+        assert not nv.lib().ss_gemm8_ok(n, cin, cout, k ** 3)
+        with pytest.raises(RuntimeError):
+            nv.subm_conv_fwd_pipe(x.to(torch.bfloat16).cuda(), wk, b.cuda(), lv.neighbors(k), lv.conv_rowperm())
+        return
+    nbr = oops.neighbor_table(gc.numpy(), batch, k)
+    yo = oops.subm_conv3d(x, w, b, nbr)
+    y = nv.subm_conv_fwd_pipe(x.to(torch.bfloat16).cuda(), wk, b.cuda(), lv.neighbors(k), lv.conv_rowperm(),
+                              torch.float32 if f32out else torch.bfloat16)
+    rel = ((y.float().cpu() - yo).norm() / yo.norm()).item()
+    assert rel < (2e-5 if f32out else 6e-3), rel
+    # identity walk order (rowperm = NULL) gives the same rows
+    y2 = nv.subm_conv_fwd_pipe(x.to(torch.bfloat16).cuda(), wk, b.cuda(), lv.neighbors(k), None, torch.float32)
+    assert ((y2.cpu() - yo).norm() / yo.norm()).item() < 2e-5
+
+
+@pytest.mark.parametrize("m,k,n,bias", [(1, 64, 4, True), (255, 64, 256, False), (257, 128, 260, True), (1000, 192, 768, True),
+                                        (3000, 4096, 36, False)])
+def test_linear_pipeline_kernel_against_fp64(m, k, n, bias):
+    """ss_linear_fwd (gemm8.hip, plain form) vs an fp64 matmul of the same bf16 operands; fp32 output is exact to
+    accumulation order, bf16 output to one rounding."""
+    from scenesplat_amd import native as nv
+    g = torch.Generator().manual_seed(m + k + n)
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16); w = (torch.randn(n, k, generator=g) * 0.1).to(torch.bfloat16)
+    b = torch.randn(n, generator=g) if bias else None
+    ref = x.double() @ w.double().t() + (b.double() if bias else 0.0)
+    y32 = nv.linear_fwd(x.cuda(), w.cuda(), b.cuda() if bias else None, torch.float32).cpu().double()
+    y16 = nv.linear_fwd(x.cuda(), w.cuda(), b.cuda() if bias else None, torch.bfloat16).cpu().double()
+    scale = ref.abs().max().item()
+    assert (y32 - ref).abs().max().item() < 2e-5 * scale
+    assert (y16 - ref).abs().max().item() < 5e-3 * scale
+    with pytest.raises(RuntimeError):       # K must be a multiple of 64
+        nv.linear_fwd(x[:, :40].contiguous().cuda(), w[:, :40].contiguous().cuda())
+
+
 def _attn_case(golden_dir, name):
     fx = np.load(os.path.join(golden_dir, "attention.npz"))
     C, H, K, oi = [int(v) for v in fx[f"{name}_cfg"]]
