@@ -450,6 +450,12 @@ extern "C" int ss_subm_conv_wgrad(const void* in, const void* dout, const int32_
                                   int cout, int taps, hipStream_t stream) {
   if (n < 0 || cin <= 0 || cout <= 0 || taps <= 0 || (cin & 7) || (cout & 7) || n >= (1LL << 31)) return SS_ERR_ARG;
   if (n == 0) return SS_OK;
+  {
+    static int mode = -2;                 // SS_WGRAD_PIPE=0/1 overrides the kernel choice
+    if (mode == -2) { const char* e = getenv("SS_WGRAD_PIPE"); mode = e ? atoi(e) : -1; }
+    if (mode != 0 && ss_wgrad8_ok(n, cin, cout, taps) && (mode == 1 || (cout >= 128 && cin >= 128)))
+      return ss_subm_conv_wgrad_pipe(in, dout, nbr, rowperm, blk_count, blk_list, dweight, n, cin, cout, taps, stream);
+  }
   const int nblocks = ss_div_up(n, 64);
   // the 256 x 256 form pays off only with long K loops per workgroup (its fp32-atomic epilogue is 4x larger)
   const bool big = cout >= 256 && cin >= 256 && nblocks >= 1024;

@@ -1,0 +1,284 @@
+// Weight-gradient GEMM on the LDS-DMA pipeline of gemm8.hip (gfx950):  256 x 256 tile, K = sites.
+//
+//   dW[co][tap][ci] += sum_i dout[i][co] * in[row_tap(i)][ci]        (fp32 atomics into a zeroed dW)
+//
+//   GATHER = true   spconv.SubMConv3d weight gradient (ptv3:278-284): row_tap(i) = nbr[tap][i] (pair skipped when
+//                   missing); per tap only the ACTIVE 64-site blocks (ss_subm_block_lists) are walked, split over
+//                   gridDim.z workgroups
+//   GATHER = false  nn.Linear weight gradient dW = dy^T x: taps = 1, row(i) = i, every block active
+//
+// Both operands are [site][channel]-major, i.e. K-strided for the MFMA.  The LDS images stay plain [site][256 B]
+// rows -- what LDS-DMA writes, 4 site rows per 1-KiB wave instruction -- and the fragments are read with
+// ds_read_b64_tr_b16 (the same k permutation on both operands).  The 16-byte chunk index is XOR-swizzled per row
+// (applied to the DMA SOURCE column, and again on the read) so the transposed reads are conflict-free.
+// Pipeline, phases, staggered wave rows and hazard rules: exactly gemm8.hip's (see its header).
+// GATHER: the (site, neighbour) ids of up to W8_CHUNK K-tiles live in LDS; longer shares are walked chunk by chunk.
+#include "common.h"
+#include "../../include/scenesplat_hip.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 w8_bf8_t;
+typedef __attribute__((ext_vector_type(4))) short w8_s4_t;
+typedef __attribute__((ext_vector_type(8))) short w8_s8_t;
+typedef __attribute__((address_space(3))) w8_s4_t w8_lds_s4_t;
+#define W8_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+#define W8_BUF 65536
+#define W8_HALF 16384
+#define W8_OFF_B 32768
+#define W8_CHUNK 60
+#define W8_OFF_ISITE 131072
+#define W8_OFF_JSITE (W8_OFF_ISITE + W8_CHUNK * 64 * 4)
+#define W8_LDS_BYTES (W8_OFF_JSITE + W8_CHUNK * 64 * 4)
+#define W8_ZERO_ELEMS 4096
+
+__device__ uint4 w8_zero[W8_ZERO_ELEMS / 8];
+
+// LDS-DMA issued as inline asm: with the builtin, hipcc (ROCm 7.2) puts s_waitcnt vmcnt(0) in front of every
+// ds_read_b64_tr_b16 (it cannot tell the transposed read from a reader of the pending DMA) and the pipeline drains
+// every phase.  Ordering is by the counted vmcnt + barriers of the schedule, as documented in gemm8.hip.
+__device__ __forceinline__ void w8_glds16(const void* gsrc, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_wave_base) : "memory");
+}
+__device__ __forceinline__ w8_bf8_t w8_tr2(const char* p) {       // k rows r0 and r0+16 of one 16-column group
+  w8_s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((w8_lds_s4_t*)(p));
+  w8_s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((w8_lds_s4_t*)(p + 16 * 256));
+  w8_s8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(w8_bf8_t, v);
+}
+
+template <bool GATHER>
+__global__ void __launch_bounds__(512)
+k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY, const int32_t* __restrict__ nbr,
+         const int32_t* __restrict__ rowperm, const int32_t* __restrict__ blk_count, const int32_t* __restrict__ blk_list,
+         float* __restrict__ dW, int n, int Cin, int Cout, int taps, int ntn, int nblocks_total, int min_per) {
+  __shared__ __attribute__((aligned(16))) char smem[GATHER ? W8_LDS_BYTES : 2 * W8_BUF];
+  int32_t* isite_s = reinterpret_cast<int32_t*>(smem + W8_OFF_ISITE);
+  int32_t* jsite_s = reinterpret_cast<int32_t*>(smem + W8_OFF_JSITE);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, g = lane >> 4;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int m0 = (blockIdx.x / ntn) * 256, n0 = (blockIdx.x % ntn) * 256;      // Cout, Cin origins
+  const int tap = blockIdx.y;
+  const int cnt = GATHER ? blk_count[tap] : nblocks_total;
+  // a share is at least min_per K-tiles (the 256 KiB fp32-atomic epilogue is paid per share); surplus workgroups exit
+  const int per = max((cnt + (int)gridDim.z - 1) / (int)gridDim.z, min_per);
+  const int beg = blockIdx.z * per, end = min(cnt, beg + per);
+  if (end <= beg) return;
+  const int32_t* list = GATHER ? blk_list + (int64_t)tap * nblocks_total : nullptr;
+
+  f32x4_t acc[2][4][2][2];                      // [A half][mi][B half][ni]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[a][mi][b][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging: wave-instruction (j, wave) fills site rows (j*8+wave)*4 + (lane>>4), 16-byte slot lane&15 ----
+  const int srow = wave * 4 + (lane >> 4);                         // + 32 j
+  const int ssw = ((lane >> 4) << 2) | (wave & 3);                 // swizzle of those rows (same for j = 0, 1)
+  const int lch = (lane & 15) ^ ssw;                               // logical chunk held by the slot
+  int colA[2], colB[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    colA[h] = min(m0 + (lch >> 3) * 128 + h * 64 + (lch & 7) * 8, Cout - 8);
+    colB[h] = min(n0 + (lch >> 2) * 64 + h * 32 + (lch & 3) * 8, Cin - 8);
+  }
+  const unsigned short* const zrow = reinterpret_cast<const unsigned short*>(w8_zero);
+  const unsigned short* pA[2];
+  const unsigned short* pB[2];
+  int chunk_beg = beg, T = 0, staged = 0;
+  auto load_rows = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (GATHER) {
+        int is = isite_s[s * 64 + srow + 32 * j], js = jsite_s[s * 64 + srow + 32 * j];
+        pA[j] = js >= 0 ? DY + (int64_t)is * Cout : zrow;
+        pB[j] = js >= 0 ? X + (int64_t)js * Cin : zrow;
+      } else {
+        int64_t k = (int64_t)(chunk_beg + s) * 64 + srow + 32 * j;
+        pA[j] = k < n ? DY + k * Cout : zrow;
+        pB[j] = k < n ? X + k * Cin : zrow;
+      }
+    }
+  };
+  auto advance = [&]() {
+    if (staged + 1 >= T) return;
+    ++staged;
+    load_rows(staged);
+  };
+  const unsigned dst0 = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + (unsigned)wave * 1024u);
+  auto stageA = [&](int buf, int h) {
+    unsigned d = dst0 + buf * W8_BUF + h * W8_HALF;
+    w8_glds16(pA[0] + colA[h], d);
+    w8_glds16(pA[1] + colA[h], d + 8192);
+  };
+  auto stageB = [&](int buf, int h) {
+    unsigned d = dst0 + buf * W8_BUF + W8_OFF_B + h * W8_HALF;
+    w8_glds16(pB[0] + colB[h], d);
+    w8_glds16(pB[1] + colB[h], d + 8192);
+  };
+
+  // ---- fragment reads: k rows 32kk + 4g + (lq>>2) (+16), 16-column group -> chunks 2i, 2i+1; swizzle is per lane ----
+  const int rsw = (((lq >> 2) & 3) << 2) | g;
+  const int rbase = (4 * g + (lq >> 2)) * 256 + 8 * (lq & 1);
+  int oA[4], oB[2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) oA[mi] = rbase + (((wr * 8 + 2 * mi + ((lq & 3) >> 1)) ^ rsw) << 4);
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) oB[ni] = W8_OFF_B + rbase + (((wc * 4 + 2 * ni + ((lq & 3) >> 1)) ^ rsw) << 4);
+  w8_bf8_t af[4][2], b0f[2][2], b1f[2][2];
+  auto readA = [&](int buf, int h) {
+    const char* base = smem + buf * W8_BUF + h * W8_HALF;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      af[mi][0] = w8_tr2(base + oA[mi]);
+      af[mi][1] = w8_tr2(base + oA[mi] + 32 * 256);
+    }
+  };
+  auto readB = [&](int buf, int h, w8_bf8_t (&bf)[2][2]) {
+    const char* base = smem + buf * W8_BUF + h * W8_HALF;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      bf[ni][0] = w8_tr2(base + oB[ni]);
+      bf[ni][1] = w8_tr2(base + oB[ni] + 32 * 256);
+    }
+  };
+#define W8_MM(HA, HB, BF)                                                                         \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                \
+  _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                \
+  _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                \
+      acc[HA][mi][HB][ni] = W8_MFMA(af[mi][ks], BF[ni][ks], acc[HA][mi][HB][ni]);
+#define W8_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define W8_COMPUTE_BEGIN() do { W8_BAR(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); } while (0)
+#define W8_COMPUTE_END() do { __builtin_amdgcn_s_setprio(0); W8_BAR(); } while (0)
+
+  for (; chunk_beg < end; chunk_beg += (GATHER ? W8_CHUNK : (1 << 30))) {
+    T = GATHER ? min(W8_CHUNK, end - chunk_beg) : end - chunk_beg;
+    if (GATHER) {
+      __syncthreads();                           // previous chunk's index reads are done
+      for (int e = tid; e < T * 64; e += 512) {
+        int k = list[chunk_beg + (e >> 6)] * 64 + (e & 63);
+        int is = k < n ? (rowperm ? rowperm[k] : k) : -1;
+        isite_s[e] = is;
+        jsite_s[e] = is >= 0 ? nbr[(int64_t)tap * n + is] : -1;
+      }
+      __syncthreads();
+    }
+    staged = 0;
+    load_rows(0);
+    // prologue: tile 0 complete + B0 A0 B1 of tile 1
+    stageB(0, 0); stageA(0, 0); stageB(0, 1); stageA(0, 1);
+    advance();
+    stageB(1, 0); stageA(1, 0); stageB(1, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    W8_BAR();
+    if (wr == 1) W8_BAR();                       // wave row 1 runs one barrier behind
+    for (int t = 0; t < T; ++t) {
+      const int buf = t & 1;
+      // ph1
+      readB(buf, 0, b0f);
+      __builtin_amdgcn_sched_barrier(0);
+      readA(buf, 0);
+      stageA(buf ^ 1, 1);                        // A1 of tile t+1
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");   // 24 reads issued, B0's 8 first: retired before the barrier
+      W8_COMPUTE_BEGIN();
+      W8_MM(0, 0, b0f)
+      W8_COMPUTE_END();
+      // ph2
+      advance();                                 // state -> tile t+2
+      readB(buf, 1, b1f);
+      stageB(buf, 0);
+      W8_COMPUTE_BEGIN();
+      W8_MM(0, 1, b1f)
+      W8_COMPUTE_END();
+      // ph3
+      readA(buf, 1);
+      stageA(buf, 0);
+      W8_COMPUTE_BEGIN();
+      W8_MM(1, 1, b1f)
+      W8_COMPUTE_END();
+      // ph4
+      stageB(buf, 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      W8_COMPUTE_BEGIN();
+      W8_MM(1, 0, b0f)
+      W8_COMPUTE_END();
+    }
+    if (wr == 0) W8_BAR();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+
+  // ---- epilogue: acc[ha][mi][hb][ni][r] = dW[co = 128wr + 64ha + 16mi + 4g + r][ci = 64wc + 32hb + 16ni + lq] ----
+#pragma unroll
+  for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = m0 + 128 * wr + 64 * ha + 16 * mi + 4 * g + r;
+        if (co >= Cout) continue;
+        float* rowp = dW + ((int64_t)co * taps + tap) * Cin;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const int ci = n0 + 64 * wc + 32 * hb + 16 * ni + lq;
+            if (ci < Cin) atomicAdd(rowp + ci, acc[ha][mi][hb][ni][r]);
+          }
+      }
+}
+
+extern "C" int ss_wgrad8_ok(int64_t n, int cin, int cout, int taps) {
+  return n > 0 && n < (1LL << 31) && cin >= 8 && (cin & 7) == 0 && cin <= W8_ZERO_ELEMS && cout >= 8 && (cout & 7) == 0 &&
+         cout <= W8_ZERO_ELEMS && taps >= 1;
+}
+
+// K-tiles per share.  Measured (scripts/tune_wgrad.py): the 256-KiB atomic epilogue and the pipeline fill make about
+// 200 shares the sweet spot until shares reach ~160 K-tiles; est_blocks = expected active blocks of a busy tile.
+static int w8_min_per(int64_t busy_tiles, int64_t est_blocks) {
+  int64_t per = busy_tiles * est_blocks / 200;
+  if (per < 8) per = 8;
+  if (per > 160) per = 160;
+  return (int)per;
+}
+
+extern "C" int ss_subm_conv_wgrad_pipe(const void* in, const void* dout, const int32_t* nbr, const int32_t* rowperm,
+                                       const int32_t* blk_count, const int32_t* blk_list, float* dweight, int64_t n,
+                                       int cin, int cout, int taps, hipStream_t stream) {
+  if (n == 0) return SS_OK;
+  if (!ss_wgrad8_ok(n, cin, cout, taps) || !blk_count || !blk_list || !nbr) return SS_ERR_ARG;
+  const int nblocks = ss_div_up(n, 64);
+  const int tm = ss_div_up(cout, 256), tn = ss_div_up(cin, 256);
+  // the active-block counts live on the device: launch enough shares for a fully active tap and let the kernel
+  // size them (>= min_per K-tiles each); on surfaces about a third of the taps carry almost all pairs
+  static int env_per = -2;
+  if (env_per == -2) { const char* e = getenv("SS_WGRAD_MINPER"); env_per = e ? atoi(e) : -1; }
+  int min_per = env_per > 0 ? env_per : w8_min_per((int64_t)tm * tn * ((taps + 2) / 3), (int64_t)nblocks * 7 / 10);
+  int splits = ss_div_up(nblocks, min_per);
+  dim3 g(tm * tn, taps, splits);
+  SS_LAUNCH((k_wgrad8<true>), g, dim3(512), 0, stream, (const unsigned short*)in, (const unsigned short*)dout, nbr, rowperm,
+            blk_count, blk_list, dweight, (int)n, cin, cout, taps, tn, nblocks, min_per);
+  return SS_OK;
+}
+
+extern "C" int ss_linear_wgrad(const void* x, const void* dy, float* dweight, int64_t m, int k_in, int n_out,
+                               hipStream_t stream) {
+  if (m == 0) return SS_OK;
+  if (!ss_wgrad8_ok(m, k_in, n_out, 1)) return SS_ERR_ARG;
+  const int nblocks = ss_div_up(m, 64);
+  const int tm = ss_div_up(n_out, 256), tn = ss_div_up(k_in, 256);
+  static int env_per = -2;
+  if (env_per == -2) { const char* e = getenv("SS_WGRAD_MINPER"); env_per = e ? atoi(e) : -1; }
+  int min_per = env_per > 0 ? env_per : w8_min_per((int64_t)tm * tn, nblocks);
+  int splits = ss_div_up(nblocks, min_per);
+  dim3 g(tm * tn, 1, splits);
+  SS_LAUNCH((k_wgrad8<false>), g, dim3(512), 0, stream, (const unsigned short*)x, (const unsigned short*)dy,
+            (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, dweight,
+            (int)m, k_in, n_out, 1, tn, nblocks, min_per);
+  return SS_OK;
+}

@@ -226,6 +226,27 @@ def subm_conv_wgrad(x, dout, nbr, rowperm, blocks):
     return dw
 
 
+def subm_conv_wgrad_pipe(x, dout, nbr, rowperm, blocks):
+    """The pipeline weight-gradient kernel directly (tests / benches)."""
+    n, cin = x.shape
+    cout, taps = dout.shape[1], nbr.shape[0]
+    dw = torch.zeros((cout, taps, cin), dtype=torch.float32, device=x.device)
+    cnt, lst = blocks
+    check(lib().ss_subm_conv_wgrad_pipe(_p(x), _p(dout), _p(nbr), _p(rowperm), _p(cnt), _p(lst), _p(dw), n, cin, cout, taps,
+                                        _stream()), "ss_subm_conv_wgrad_pipe")
+    return dw
+
+
+def linear_wgrad(x, dy):
+    """dW (n_out,k_in) f32 = dy^T @ x on the pipeline kernel.  x (m,k_in) bf16, dy (m,n_out) bf16."""
+    m, k = x.shape
+    nout = dy.shape[1]
+    _req(x, torch.bfloat16, "x"); _req(dy, torch.bfloat16, "dy", (m, nout))
+    dw = torch.zeros((nout, k), dtype=torch.float32, device=x.device)
+    check(lib().ss_linear_wgrad(_p(x), _p(dy), _p(dw), m, k, nout, _stream()), "ss_linear_wgrad")
+    return dw
+
+
 # ---- fused add + layernorm ----------------------------------------------------------------------
 def _dt(t):
     return dtype_code(t) if t is not None else 0

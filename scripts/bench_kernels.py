@@ -45,6 +45,12 @@ def main():
             blocks = lv.conv_blocks(3)
             tw = ev(lambda: nv.subm_conv_wgrad(x, gout, nbr, perm, blocks), 5, 2)
             fl = 2.0 * n * act * C * C
+            if nv.lib().ss_wgrad8_ok(n, C, C, 27):
+                refw = nv.subm_conv_wgrad(x, gout, nbr, perm, blocks)
+                gotw = nv.subm_conv_wgrad_pipe(x, gout, nbr, perm, blocks)
+                errw = (gotw - refw).abs().max().item() / refw.abs().max().item()
+                tw2 = ev(lambda: nv.subm_conv_wgrad_pipe(x, gout, nbr, perm, blocks), 5, 2)
+                print(f"   pipe kernel: wgrad {tw2:.3f} ms ({fl/tw2/1e9:.0f} TF/s)  rel err vs dispatch {errw:.2e}", flush=True)
             if nv.lib().ss_gemm8_ok(n, C, C, 27):
                 ref = nv.subm_conv_fwd(x, w, None, nbr, perm).float()
                 got = nv.subm_conv_fwd_pipe(x, w, None, nbr, perm).float()
@@ -72,6 +78,11 @@ def gemm():
         t2 = ev(lambda: dy @ w, 10, 3)                       # dgrad, NN
         t3 = ev(lambda: nv.linear_fwd(dy, wt), 10, 3)        # dgrad on the pipe kernel with W^T
         t4 = ev(lambda: dy.t() @ x, 10, 3)                   # wgrad, TN
+        refw = (dy.t() @ x).float()
+        gotw = nv.linear_wgrad(x, dy)
+        errw = (gotw - refw).abs().max().item() / refw.abs().max().item()
+        t5 = ev(lambda: nv.linear_wgrad(x, dy), 10, 3)
+        print(f"   wgrad pipe {t5:.3f} ms ({2.0*m*k*n/t5/1e9:.0f} TF/s) rel err {errw:.2e}", flush=True)
         fl = 2.0 * m * k * n
         print(f"   dgrad hipBLASLt {t2:.3f} ms ({fl/t2/1e9:.0f} TF/s) pipe(W^T) {t3:.3f} ms ({fl/t3/1e9:.0f} TF/s) | wgrad hipBLASLt {t4:.3f} ms ({fl/t4/1e9:.0f} TF/s)", flush=True)
         print(f"gemm m={m} k={k} n={n}: hipBLASLt {t0:.3f} ms ({fl/t0/1e9:.0f} TF/s)  pipe {t1:.3f} ms ({fl/t1/1e9:.0f} TF/s)  rel err {err:.2e}", flush=True)
