@@ -181,6 +181,49 @@ def subm_conv3d(feat, weight, bias, nbr, has_dup=False, compute_dtype=torch.floa
     return _SubMConv3d.apply(feat, weight, bias, nbr, has_dup, compute_dtype)
 
 
+class _Linear(torch.autograd.Function):
+    """nn.Linear under bf16 autocast.  Forward and dgrad stay on hipBLASLt (NT / NN forms run at 0.9-1.3 PFLOP/s
+    there); the weight gradient dy^T x -- K = sites, 0.25-0.7 PFLOP/s in hipBLASLt's TN form -- runs on the
+    LDS-DMA pipeline kernel (csrc/wgrad8.hip) and lands in fp32 directly, without the bf16 -> fp32 grad cast."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        w16 = weight.to(torch.bfloat16)
+        y = torch.nn.functional.linear(x, w16, None if bias is None else bias.to(torch.bfloat16))
+        ctx.save_for_backward(x, w16)
+        ctx.meta = (weight.dtype, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w16 = ctx.saved_tensors
+        w_dtype, has_bias = ctx.meta
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dy @ w16
+        if ctx.needs_input_grad[1]:
+            m, k = x.shape
+            if m >= LINEAR_WGRAD_MIN_ROWS and nv.lib().ss_wgrad8_ok(m, k, dy.shape[1], 1):
+                dw = nv.linear_wgrad(x, dy).to(w_dtype)
+            else:
+                dw = (dy.t() @ x).to(w_dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0, dtype=torch.float32).to(w_dtype)
+        return dx, dw, db
+
+
+LINEAR_WGRAD_MIN_ROWS = 4096
+
+
+def linear(x, weight, bias=None):
+    """torch.nn.functional.linear; under CUDA bf16 autocast on 2-D input the backward uses the pipeline wgrad kernel."""
+    if x.is_cuda and x.dim() == 2 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16 \
+            and weight.dtype == torch.float32:
+        return _Linear.apply(x.to(torch.bfloat16).contiguous(), weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
 class _LayerNorm(torch.autograd.Function):
     """h = LN(x) in one pass, bf16 or fp32 out (csrc/norm.hip)."""
 

@@ -69,6 +69,11 @@ class SubMConv3d(nn.Module):
                               lambda: level.conv_blocks(self.kernel_size))
 
 
+def _lin(mod, x):
+    """nn.Linear through SF.linear (pipeline weight-gradient kernel under bf16 autocast)."""
+    return SF.linear(x, mod.weight, mod.bias)
+
+
 class SerializedAttention(PointModule):
     def __init__(self, channels, num_heads, patch_size, qkv_bias=True, qk_scale=None, attn_drop=0.0,
                  proj_drop=0.0, order_index=0, enable_rpe=False, enable_flash=True, upcast_attention=True,
@@ -87,13 +92,13 @@ class SerializedAttention(PointModule):
 
     def forward(self, x, level):
         win = level.window(self.order_index, self.patch_size)
-        qkv = self.qkv(x)
+        qkv = _lin(self.qkv, x)
         impl = RUNTIME["attn_impl"]
         if impl == nv.ATTN_MFMA and qkv.dtype != torch.bfloat16:
             feat = SF.window_attention(qkv.to(torch.bfloat16), win, self.num_heads, self.scale, impl).to(qkv.dtype)
         else:
             feat = SF.window_attention(qkv, win, self.num_heads, self.scale, impl)
-        return self.proj(feat)
+        return _lin(self.proj, feat)
 
 
 class MLP(nn.Module):
@@ -106,7 +111,7 @@ class MLP(nn.Module):
         self.fc2 = nn.Linear(hidden_channels, out_channels)
 
     def forward(self, x):
-        return self.fc2(self.act(self.fc1(x)))
+        return _lin(self.fc2, self.act(_lin(self.fc1, x)))
 
 
 class Block(PointModule):
@@ -133,7 +138,7 @@ class Block(PointModule):
             return self._forward_post_norm(x, conv_in, level), None
         hdt = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
         ln0, ln1, ln2 = self.cpe[2], self.norm1[0], self.norm2[0]
-        t = self.cpe[1](self.cpe[0](conv_in, level))
+        t = _lin(self.cpe[1], self.cpe[0](conv_in, level))
         t = SF.layer_norm(t, ln0.weight, ln0.bias, ln0.eps)
         x, h, _ = SF.add_layer_norm(x, t, None, ln1.weight, ln1.bias, ln1.eps, False, hdt)
         x, h, _ = SF.add_layer_norm(x, self.attn(h, level), self._row_scale(x), ln2.weight, ln2.bias, ln2.eps, False, hdt)
@@ -167,7 +172,7 @@ def _norm_act(x, norm, act):
 def _seq_lin_norm_act(seq, x):
     """nn.Sequential(Linear[, BatchNorm1d][, GELU]) with the norm/act pair fused."""
     mods = list(seq)
-    x = mods[0](x)
+    x = _lin(mods[0], x) if isinstance(mods[0], nn.Linear) else mods[0](x)
     norm = mods[1] if len(mods) > 1 and isinstance(mods[1], nn.BatchNorm1d) else None
     act = mods[-1] if len(mods) > 1 and isinstance(mods[-1], nn.GELU) else None
     if norm is None and act is None:
@@ -191,7 +196,7 @@ class SerializedPooling(PointModule):
         self.act = act_layer() if act_layer is not None else None
 
     def forward(self, x, coarse_level):
-        x = SF.segment_mean(self.proj(x), coarse_level, mean=(self.reduce == "mean"))
+        x = SF.segment_mean(_lin(self.proj, x), coarse_level, mean=(self.reduce == "mean"))
         return _norm_act(x, self.norm[0] if self.norm is not None else None, self.act)
 
 

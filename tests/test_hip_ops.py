@@ -195,6 +195,35 @@ def test_linear_pipeline_kernel_against_fp64(m, k, n, bias):
         nv.linear_fwd(x[:, :40].contiguous().cuda(), w[:, :40].contiguous().cuda())
 
 
+@pytest.mark.parametrize("m,k,n,bias", [(5000, 64, 192, True), (4100, 136, 72, False), (300, 64, 64, True)])
+def test_linear_autograd_matches_torch_autocast(m, k, n, bias):
+    """SF.linear under bf16 autocast: same forward / dx as torch's autocast F.linear, weight and bias gradients equal to
+    the fp64 result of the same bf16 operands (they are fp32-accumulated and never rounded to bf16)."""
+    from scenesplat_amd import functional as SF
+    g = torch.Generator().manual_seed(m + n)
+    x = torch.randn(m, k, generator=g).cuda(); w = (torch.randn(n, k, generator=g) * 0.1).cuda(); b = torch.randn(n, generator=g).cuda() if bias else None
+    cot = torch.randn(m, n, generator=g).cuda().to(torch.bfloat16)
+    outs = []
+    for fn in (SF.linear, torch.nn.functional.linear):
+        xi, wi = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        bi = b.clone().requires_grad_(True) if bias else None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = fn(xi, wi, bi)
+        y.backward(cot)
+        outs.append((y, xi.grad, wi.grad, bi.grad if bias else None))
+    (y0, dx0, dw0, db0), (y1, dx1, dw1, db1) = outs
+    assert y0.dtype == torch.bfloat16 and torch.equal(y0, y1)
+    assert torch.allclose(dx0, dx1, atol=1e-2, rtol=1e-2)
+    assert dw0.dtype == torch.float32
+    ref_dw = cot.double().t() @ x.to(torch.bfloat16).double()
+    tol = 1e-4 if m >= SF.LINEAR_WGRAD_MIN_ROWS else 1e-2      # below the threshold hipBLASLt's bf16 result is used
+    assert (dw0.double() - ref_dw).abs().max().item() < tol * ref_dw.abs().max().item() + 1e-5
+    assert (dw1.double() - ref_dw).abs().max().item() < 1e-2 * ref_dw.abs().max().item()
+    if bias:
+        ref_db = cot.double().sum(0)
+        assert (db0.double() - ref_db).abs().max().item() < 1e-4 * ref_db.abs().max().item() + 1e-5
+
+
 def _attn_case(golden_dir, name):
     fx = np.load(os.path.join(golden_dir, "attention.npz"))
     C, H, K, oi = [int(v) for v in fx[f"{name}_cfg"]]
