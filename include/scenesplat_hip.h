@@ -102,12 +102,14 @@ int ss_linear_fwd(const void* x, const void* weight, const float* bias, void* ou
                   ss_stream_t stream);
 /* weight gradients on the same pipeline (csrc/wgrad8.hip); dweight must be ZERO on entry (fp32 atomics).
  * ss_subm_conv_wgrad_pipe: contract of ss_subm_conv_wgrad (which dispatches to it for wide, large levels).
- * ss_linear_wgrad: dweight (n_out,k_in) f32 += dy (m,n_out)^T @ x (m,k_in), both bf16 -- the nn.Linear weight gradient. */
+ * ss_linear_wgrad: dweight (n_out,k_in) f32 += dy (m,n_out)^T @ x (m,k_in), both bf16 -- the nn.Linear weight gradient;
+ * dbias (n_out) f32, ZERO on entry, += column sums of dy (the bias gradient), or NULL. */
 int ss_wgrad8_ok(int64_t n, int cin, int cout, int taps);
 int ss_subm_conv_wgrad_pipe(const void* in, const void* dout, const int32_t* nbr, const int32_t* rowperm,
                             const int32_t* blk_count, const int32_t* blk_list, float* dweight, int64_t n, int cin, int cout,
                             int taps, ss_stream_t stream);
-int ss_linear_wgrad(const void* x, const void* dy, float* dweight, int64_t m, int k_in, int n_out, ss_stream_t stream);
+int ss_linear_wgrad(const void* x, const void* dy, float* dweight, float* dbias, int64_t m, int k_in, int n_out,
+                    ss_stream_t stream);
 /* small levels: split-K over tap ranges; acc32 (n,cout) f32 zeroed by the caller, receives out (+bias) */
 int ss_subm_conv_splits(int64_t n, int cout, int taps);
 int ss_subm_conv_fwd_splitk(const void* in, const void* weight, const float* bias, const int32_t* nbr, const int32_t* rowperm,

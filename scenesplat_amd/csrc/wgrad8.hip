@@ -51,7 +51,8 @@ template <bool GATHER>
 __global__ void __launch_bounds__(512)
 k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY, const int32_t* __restrict__ nbr,
          const int32_t* __restrict__ rowperm, const int32_t* __restrict__ blk_count, const int32_t* __restrict__ blk_list,
-         float* __restrict__ dW, int n, int Cin, int Cout, int taps, int ntn, int nblocks_total, int min_per) {
+         float* __restrict__ dW, float* __restrict__ dbias, int n, int Cin, int Cout, int taps, int ntn, int nblocks_total,
+         int min_per) {
   __shared__ __attribute__((aligned(16))) char smem[GATHER ? W8_LDS_BYTES : 2 * W8_BUF];
   int32_t* isite_s = reinterpret_cast<int32_t*>(smem + W8_OFF_ISITE);
   int32_t* jsite_s = reinterpret_cast<int32_t*>(smem + W8_OFF_JSITE);
@@ -75,6 +76,16 @@ k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict_
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc[a][mi][b][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // column sums of dout (the bias gradient) ride along in the workgroups of the first Cin tile: wave column wc adds
+  // its 16-channel group mi = wc of both A halves with an all-ones B fragment (4 extra MFMAs per K-tile)
+  const bool do_bias = !GATHER && dbias != nullptr && (blockIdx.x % ntn) == 0;
+  f32x4_t accb[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+  w8_bf8_t ones;
+  {
+    w8_s8_t o = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    ones = __builtin_bit_cast(w8_bf8_t, o);
+  }
 
   // ---- staging: wave-instruction (j, wave) fills site rows (j*8+wave)*4 + (lane>>4), 16-byte slot lane&15 ----
   const int srow = wave * 4 + (lane >> 4);                         // + 32 j
@@ -152,6 +163,13 @@ k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict_
   _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                \
   _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                \
       acc[HA][mi][HB][ni] = W8_MFMA(af[mi][ks], BF[ni][ks], acc[HA][mi][HB][ni]);
+#define W8_BIAS(HA)                                                                               \
+  if (do_bias) {                                                                                  \
+    if (wc == 0) { accb[HA] = W8_MFMA(af[0][0], ones, accb[HA]); accb[HA] = W8_MFMA(af[0][1], ones, accb[HA]); }       \
+    else if (wc == 1) { accb[HA] = W8_MFMA(af[1][0], ones, accb[HA]); accb[HA] = W8_MFMA(af[1][1], ones, accb[HA]); }  \
+    else if (wc == 2) { accb[HA] = W8_MFMA(af[2][0], ones, accb[HA]); accb[HA] = W8_MFMA(af[2][1], ones, accb[HA]); }  \
+    else { accb[HA] = W8_MFMA(af[3][0], ones, accb[HA]); accb[HA] = W8_MFMA(af[3][1], ones, accb[HA]); }              \
+  }
 #define W8_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define W8_COMPUTE_BEGIN() do { W8_BAR(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); } while (0)
 #define W8_COMPUTE_END() do { __builtin_amdgcn_s_setprio(0); W8_BAR(); } while (0)
@@ -195,6 +213,7 @@ k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict_
       stageB(buf, 0);
       W8_COMPUTE_BEGIN();
       W8_MM(0, 1, b1f)
+      W8_BIAS(0)
       W8_COMPUTE_END();
       // ph3
       readA(buf, 1);
@@ -207,6 +226,7 @@ k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict_
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       W8_COMPUTE_BEGIN();
       W8_MM(1, 0, b0f)
+      W8_BIAS(1)
       W8_COMPUTE_END();
     }
     if (wr == 0) W8_BAR();
@@ -231,8 +251,18 @@ k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict_
             if (ci < Cin) atomicAdd(rowp + ci, acc[ha][mi][hb][ni][r]);
           }
       }
+  if (do_bias && lq == 0) {
+#pragma unroll
+    for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = m0 + 128 * wr + 64 * ha + 16 * wc + 4 * g + r;
+        if (co < Cout) atomicAdd(dbias + co, accb[ha][r]);
+      }
+  }
 }
 
+#undef W8_BIAS
 extern "C" int ss_wgrad8_ok(int64_t n, int cin, int cout, int taps) {
   return n > 0 && n < (1LL << 31) && cin >= 8 && (cin & 7) == 0 && cin <= W8_ZERO_ELEMS && cout >= 8 && (cout & 7) == 0 &&
          cout <= W8_ZERO_ELEMS && taps >= 1;
@@ -262,11 +292,11 @@ extern "C" int ss_subm_conv_wgrad_pipe(const void* in, const void* dout, const i
   int splits = ss_div_up(nblocks, min_per);
   dim3 g(tm * tn, taps, splits);
   SS_LAUNCH((k_wgrad8<true>), g, dim3(512), 0, stream, (const unsigned short*)in, (const unsigned short*)dout, nbr, rowperm,
-            blk_count, blk_list, dweight, (int)n, cin, cout, taps, tn, nblocks, min_per);
+            blk_count, blk_list, dweight, (float*)nullptr, (int)n, cin, cout, taps, tn, nblocks, min_per);
   return SS_OK;
 }
 
-extern "C" int ss_linear_wgrad(const void* x, const void* dy, float* dweight, int64_t m, int k_in, int n_out,
+extern "C" int ss_linear_wgrad(const void* x, const void* dy, float* dweight, float* dbias, int64_t m, int k_in, int n_out,
                                hipStream_t stream) {
   if (m == 0) return SS_OK;
   if (!ss_wgrad8_ok(m, k_in, n_out, 1)) return SS_ERR_ARG;
@@ -279,6 +309,6 @@ extern "C" int ss_linear_wgrad(const void* x, const void* dy, float* dweight, in
   dim3 g(tm * tn, 1, splits);
   SS_LAUNCH((k_wgrad8<false>), g, dim3(512), 0, stream, (const unsigned short*)x, (const unsigned short*)dy,
             (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, dweight,
-            (int)m, k_in, n_out, 1, tn, nblocks, min_per);
+            dbias, (int)m, k_in, n_out, 1, tn, nblocks, min_per);
   return SS_OK;
 }

@@ -202,13 +202,19 @@ class _Linear(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = dy @ w16
+        want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             m, k = x.shape
             if m >= LINEAR_WGRAD_MIN_ROWS and nv.lib().ss_wgrad8_ok(m, k, dy.shape[1], 1):
-                dw = nv.linear_wgrad(x, dy).to(w_dtype)
+                if want_db:                      # column sums of dy ride along in the wgrad kernel
+                    dw, db = nv.linear_wgrad(x, dy, True)
+                    dw, db = dw.to(w_dtype), db.to(w_dtype)
+                    want_db = False
+                else:
+                    dw = nv.linear_wgrad(x, dy).to(w_dtype)
             else:
                 dw = (dy.t() @ x).to(w_dtype)
-        if has_bias and ctx.needs_input_grad[2]:
+        if want_db:
             db = dy.sum(0, dtype=torch.float32).to(w_dtype)
         return dx, dw, db
 

@@ -237,14 +237,17 @@ def subm_conv_wgrad_pipe(x, dout, nbr, rowperm, blocks):
     return dw
 
 
-def linear_wgrad(x, dy):
-    """dW (n_out,k_in) f32 = dy^T @ x on the pipeline kernel.  x (m,k_in) bf16, dy (m,n_out) bf16."""
+def linear_wgrad(x, dy, want_bias=False):
+    """dW (n_out,k_in) f32 = dy^T @ x on the pipeline kernel (and db (n_out) f32 = column sums of dy when want_bias).
+    x (m,k_in) bf16, dy (m,n_out) bf16.  dW and db share one zero-filled allocation."""
     m, k = x.shape
     nout = dy.shape[1]
     _req(x, torch.bfloat16, "x"); _req(dy, torch.bfloat16, "dy", (m, nout))
-    dw = torch.zeros((nout, k), dtype=torch.float32, device=x.device)
-    check(lib().ss_linear_wgrad(_p(x), _p(dy), _p(dw), m, k, nout, _stream()), "ss_linear_wgrad")
-    return dw
+    buf = torch.zeros(nout * k + (nout if want_bias else 0), dtype=torch.float32, device=x.device)
+    dw = buf[:nout * k].view(nout, k)
+    db = buf[nout * k:] if want_bias else None
+    check(lib().ss_linear_wgrad(_p(x), _p(dy), _p(dw), _p(db), m, k, nout, _stream()), "ss_linear_wgrad")
+    return (dw, db) if want_bias else dw
 
 
 # ---- fused add + layernorm ----------------------------------------------------------------------
@@ -286,13 +289,15 @@ def add_layernorm_bwd(g_xout, g_xcopy, g_h, v, mean, rstd, gamma, rowscale, gx_d
     nb = lib().ss_add_layernorm_bwd_blocks(n)
     dgp = dbp = None
     if g_h is not None:
-        dgp = torch.empty((nb, C), dtype=torch.float32, device=dev); dbp = torch.empty((nb, C), dtype=torch.float32, device=dev)
+        part = torch.empty((2, nb, C), dtype=torch.float32, device=dev)     # one allocation, ONE reduction for both
+        dgp, dbp = part[0], part[1]
         _req(v, None, "v", (n, C))
     check(lib().ss_add_layernorm_bwd(_p(g_xout), _dt(g_xout), _p(g_xcopy), _dt(g_xcopy), _p(g_h), _dt(g_h), _p(v), _dt(v),
                                      _p(mean), _p(rstd), _p(gamma), _p(rowscale), _p(g_x), _dt(g_x), _p(g_y), _dt(g_y),
                                      _p(dgp), _p(dbp), n, C, nb, _stream()), "ss_add_layernorm_bwd")
     if g_h is not None:
-        return g_x, g_y, dgp.sum(0), dbp.sum(0)
+        red = part.sum(1)
+        return g_x, g_y, red[0], red[1]
     return g_x, g_y, None, None
 
 
@@ -302,9 +307,11 @@ def col_stats(x, shift=None):
     n, C = x.shape
     _req(x, None, "x")
     nb = lib().ss_add_layernorm_bwd_blocks(n)
-    ps = torch.empty((nb, C), dtype=torch.float32, device=x.device); pq = torch.empty_like(ps)
+    part = torch.empty((2, nb, C), dtype=torch.float32, device=x.device)
+    ps, pq = part[0], part[1]
     check(lib().ss_col_stats(_p(x), _dt(x), _p(shift), _p(ps), _p(pq), n, C, nb, _stream()), "ss_col_stats")
-    return ps.sum(0), pq.sum(0)
+    red = part.sum(1)
+    return red[0], red[1]
 
 
 def bn_act_fwd(x, mean, rstd, gamma, beta, act, out_dtype):
@@ -320,10 +327,12 @@ def bn_act_bwd(dy, x, mean, rstd, gamma, beta, act, training):
     n, C = x.shape
     _req(dy, None, "dy", (n, C))
     nb = lib().ss_add_layernorm_bwd_blocks(n)
-    pz = torch.empty((nb, C), dtype=torch.float32, device=x.device); pzx = torch.empty_like(pz)
+    part = torch.empty((2, nb, C), dtype=torch.float32, device=x.device)
+    pz, pzx = part[0], part[1]
     check(lib().ss_bn_act_bwd_reduce(_p(dy), _dt(dy), _p(x), _dt(x), _p(mean), _p(rstd), _p(gamma), _p(beta), int(act), _p(pz),
                                      _p(pzx), n, C, nb, _stream()), "ss_bn_act_bwd_reduce")
-    sdz, sdzx = pz.sum(0), pzx.sum(0)
+    red = part.sum(1)
+    sdz, sdzx = red[0], red[1]
     c1 = (sdz / n).contiguous() if training else None
     c2 = (sdzx / n).contiguous() if training else None
     dx = torch.empty_like(x)
