@@ -14,6 +14,7 @@ extern "C" int ss_window_attn_fwd(const void* qkv, const int32_t* gidx, const in
   if (num_windows < 0 || channels <= 0 || num_heads <= 0 || channels % num_heads || n_pad < n) return SS_ERR_ARG;
   if (dtype != SS_F32 && dtype != SS_BF16) return SS_ERR_ARG;
   if (num_windows == 0) return SS_OK;
+  if (impl == SS_ATTN_MFMA && max_window > SS_ATTN_MFMA_MAX_WINDOW) impl = SS_ATTN_SIMT;   // index copy does not fit LDS
   if (impl == SS_ATTN_SIMT)
     return ss_attn_fwd_simt(qkv, gidx, sidx, win_start, num_windows, out, lse, channels, num_heads, scale, dtype, stream);
   if (impl == SS_ATTN_MFMA && dtype == SS_BF16)
@@ -39,6 +40,7 @@ extern "C" int ss_window_attn_bwd(const void* qkv, const void* out, const void* 
   void* extra = (char*)workspace + al256((size_t)n_pad * num_heads * 4);
   int rc = ss_attn_delta(out, dout, sidx, delta, n_pad, channels, num_heads, dtype, stream);
   if (rc) return rc;
+  if (impl == SS_ATTN_MFMA && max_window > SS_ATTN_MFMA_MAX_WINDOW) impl = SS_ATTN_SIMT;
   if (impl == SS_ATTN_SIMT)
     rc = ss_attn_bwd_simt(qkv, dout, lse, delta, gidx, sidx, win_start, num_windows, dqkv, extra, channels, num_heads,
                           scale, dtype, stream);

@@ -1,5 +1,6 @@
 #pragma once
 #include "common.h"
+#define SS_ATTN_MFMA_MAX_WINDOW 2048   // = FA_IDX_CAP of attention_mfma.hip; longer windows run on the SIMT kernels
 int ss_attn_fwd_simt(const void* qkv, const int32_t* gidx, const int32_t* sidx, const int32_t* win_start, int W,
                      void* out, float* lse, int C, int H, float scale, int dtype, hipStream_t st);
 int ss_attn_delta(const void* out, const void* dout, const int32_t* sidx, float* delta, int64_t n_pad, int C, int H,

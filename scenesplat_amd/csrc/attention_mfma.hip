@@ -84,11 +84,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {   // bijective: bloc
 #define FA_WQ (16 * FA_NT)            // rows (queries / keys) per wave
 #define FA_BQ (FA_WQ * FA_WAVES)      // 256 rows per workgroup
 #define FA_BK 64
+#define FA_IDX_CAP SS_ATTN_MFMA_MAX_WINDOW   // longest window whose gather rows fit the LDS copy (launchers refuse longer ones)
 
 // stage a 64-row K/V tile (rows gidx[p0+r0 .. +63], column block `colofs`) into registers
+// gidx_w: the window's gather rows, copied to LDS once per workgroup (FA_IDX_CAP) -- a per-step global index load
+// followed by the dependent row load put a full memory round trip (s_waitcnt vmcnt(0)) inside every step
 template <int D, int NLD>
 __device__ __forceinline__ void tile_load(uint4 (&reg)[NLD], const unsigned short* __restrict__ qkv,
-                                          const int32_t* __restrict__ gidx, int p0, int r0, int L, int64_t C3,
+                                          const int32_t* gidx_w, int r0, int L, int64_t C3,
                                           int colofs_a, int colofs_b, int tid) {
   constexpr int CH = ACfg<D>::CH;
 #pragma unroll
@@ -101,7 +104,7 @@ __device__ __forceinline__ void tile_load(uint4 (&reg)[NLD], const unsigned shor
     // (K) or multiplied by p = 0 (V), so no zero fill and no divergent branch
     uint4 v = make_uint4(0, 0, 0, 0);
     if ((2 * 64 * CH) % FA_THREADS == 0 || c < 2 * 64 * CH) {
-      int64_t row = gidx[p0 + min(r0 + r, L - 1)];
+      int64_t row = gidx_w[min(r0 + r, L - 1)];
       v = ld16(qkv + row * C3 + (second ? colofs_b : colofs_a) + ch * 8);
     }
     reg[i] = v;
@@ -121,12 +124,15 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
   constexpr int NLD = (2 * 64 * A::CH + FA_THREADS - 1) / FA_THREADS;     // 16-B loads per thread per K+V tile
   constexpr int KIMG = 64 * A::ROWB, VIMG = 64 * A::TRB;
   __shared__ __attribute__((aligned(16))) char smem[2 * (KIMG + VIMG)];
+  __shared__ int32_t gidx_s[FA_IDX_CAP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, g = lane >> 4;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int qc = lid % qchunks; const int t_ = lid / qchunks; const int h = t_ % H; const int w = t_ / H;
   const int p0 = win_start[w], L = win_start[w + 1] - p0;
   const int q0 = qc * FA_BQ;
   if (q0 >= L) return;
+  for (int i = tid; i < L; i += FA_THREADS) gidx_s[i] = gidx[p0 + i];
+  __syncthreads();
   const int64_t C3 = 3 * (int64_t)C;
   const float c2 = scale * 1.44269504088896340736f;
   auto Kbuf = [&](int b_) { return smem + b_ * (KIMG + VIMG); };
@@ -166,8 +172,10 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
 #pragma unroll
     for (int dt = 0; dt < A::NDT; ++dt) o[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
-  uint4 stage[NLD];
-  auto stage_write = [&](int b) {
+  // two register stages: the tile written to LDS at the bottom of step t was requested two steps earlier
+  // (one step of ~30 MFMAs does not cover a gathered-row fetch under load)
+  uint4 stA[NLD], stB[NLD];
+  auto stage_write = [&](uint4 (&stage)[NLD], int b) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       int c = i * FA_THREADS + tid;
@@ -179,13 +187,14 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
       else *reinterpret_cast<uint4*>(Kbuf(b) + row_img_off<D>(r, ch)) = stage[i];
     }
   };
-  tile_load<D, NLD>(stage, qkv, gidx, p0, 0, L, C3, C + h * D, 2 * C + h * D, tid);
-  stage_write(0);
-  __syncthreads();
   const int ntiles = (L + FA_BK - 1) / FA_BK;
-  for (int t = 0; t < ntiles; ++t) {
+  tile_load<D, NLD>(stA, qkv, gidx_s, 0, L, C3, C + h * D, 2 * C + h * D, tid);
+  stage_write(stA, 0);
+  if (ntiles > 1) tile_load<D, NLD>(stA, qkv, gidx_s, FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
+  if (ntiles > 2) tile_load<D, NLD>(stB, qkv, gidx_s, 2 * FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
+  __syncthreads();
+  auto step = [&](const int t, uint4 (&stage)[NLD]) {      // stage holds tile t+1
     const int b = t & 1, kv0 = t * FA_BK;
-    if (t + 1 < ntiles) tile_load<D, NLD>(stage, qkv, gidx, p0, kv0 + FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
     // ---- S^T = K Q^T : s[kt][qt], rows = keys 16kt + 4g + r, col = query lq
     f32x4_t s[4][FA_NT];
 #pragma unroll
@@ -252,8 +261,13 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
         for (int qt = 0; qt < FA_NT; ++qt) o[dt][qt] = MFMA16(vf, pf[qt], o[dt][qt]);
       }
     }
-    if (t + 1 < ntiles) stage_write(b ^ 1);
+    if (t + 1 < ntiles) stage_write(stage, b ^ 1);
+    if (t + 3 < ntiles) tile_load<D, NLD>(stage, qkv, gidx_s, kv0 + 3 * FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
     __syncthreads();
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    step(t, stA);
+    if (t + 1 < ntiles) step(t + 1, stB);
   }
   // ---- epilogue
 #pragma unroll
@@ -293,12 +307,15 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
   constexpr int RIMG = 64 * A::ROWB, TIMG = 64 * A::TRB;
   constexpr int BUF = 2 * RIMG + TIMG;      // K row image, V row image, K tr image
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  __shared__ int32_t gidx_s[FA_IDX_CAP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, g = lane >> 4;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int qc = lid % qchunks; const int t_ = lid / qchunks; const int h = t_ % H; const int w = t_ / H;
   const int p0 = win_start[w], L = win_start[w + 1] - p0;
   const int q0 = qc * FA_BQ;
   if (q0 >= L) return;
+  for (int i = tid; i < L; i += FA_THREADS) gidx_s[i] = gidx[p0 + i];
+  __syncthreads();
   const int64_t C3 = 3 * (int64_t)C;
   const float c2 = scale * 1.44269504088896340736f;
   if (A::CHP > A::CH) {
@@ -333,8 +350,8 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
   for (int qt = 0; qt < FA_NT; ++qt)
 #pragma unroll
     for (int dt = 0; dt < A::NDT; ++dt) dq[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  uint4 stage[NLD];
-  auto stage_write = [&](int b) {
+  uint4 stA[NLD], stB[NLD];
+  auto stage_write = [&](uint4 (&stage)[NLD], int b) {
     char* base = smem + b * BUF;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -350,14 +367,15 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
       }
     }
   };
-  tile_load<D, NLD>(stage, qkv, gidx, p0, 0, L, C3, C + h * D, 2 * C + h * D, tid);
-  stage_write(0);
-  __syncthreads();
   const int ntiles = (L + FA_BK - 1) / FA_BK;
-  for (int t = 0; t < ntiles; ++t) {
+  tile_load<D, NLD>(stA, qkv, gidx_s, 0, L, C3, C + h * D, 2 * C + h * D, tid);
+  stage_write(stA, 0);
+  if (ntiles > 1) tile_load<D, NLD>(stA, qkv, gidx_s, FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
+  if (ntiles > 2) tile_load<D, NLD>(stB, qkv, gidx_s, 2 * FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
+  __syncthreads();
+  auto step = [&](const int t, uint4 (&stage)[NLD]) {        // stage holds tile t+1
     const int b = t & 1, kv0 = t * FA_BK;
     const char* Kr = smem + b * BUF; const char* Vr = Kr + RIMG; const char* Kt = Kr + 2 * RIMG;
-    if (t + 1 < ntiles) tile_load<D, NLD>(stage, qkv, gidx, p0, kv0 + FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
     f32x4_t s[4][FA_NT], dp[4][FA_NT];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -399,8 +417,13 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
         for (int qt = 0; qt < FA_NT; ++qt) dq[dt][qt] = MFMA16(kf, df[qt], dq[dt][qt]);
       }
     }
-    if (t + 1 < ntiles) stage_write(b ^ 1);
+    if (t + 1 < ntiles) stage_write(stage, b ^ 1);
+    if (t + 3 < ntiles) tile_load<D, NLD>(stage, qkv, gidx_s, kv0 + 3 * FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
     __syncthreads();
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    step(t, stA);
+    if (t + 1 < ntiles) step(t + 1, stB);
   }
 #pragma unroll
   for (int qt = 0; qt < FA_NT; ++qt) {
@@ -436,12 +459,15 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
   constexpr int RIMG = FA_BQ2 * A::ROWB, TIMG = FA_BQ2 * A::TRB;
   constexpr int BUF = 2 * RIMG + 2 * TIMG + 2 * FA_BQ2 * 4;   // Q row, dO row, Q tr, dO tr, lse2[32], delta[32]
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  __shared__ int32_t gidx_s[FA_IDX_CAP], sidx_s[FA_IDX_CAP];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, g = lane >> 4;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int kc = lid % kchunks; const int t_ = lid / kchunks; const int h = t_ % H; const int w = t_ / H;
   const int p0 = win_start[w], L = win_start[w + 1] - p0;
   const int k0 = kc * FA_BQ;
   if (k0 >= L) return;
+  for (int i = tid; i < L; i += FA_THREADS) { gidx_s[i] = gidx[p0 + i]; sidx_s[i] = sidx[p0 + i]; }
+  __syncthreads();
   const int64_t C3 = 3 * (int64_t)C;
   const float c2 = scale * 1.44269504088896340736f;
   if (A::CHP > A::CH) {
@@ -472,9 +498,13 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
   for (int kt = 0; kt < FA_NT; ++kt)
 #pragma unroll
     for (int dt = 0; dt < A::NDT; ++dt) { dk[dt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
-  uint4 stage[NLD];
-  float st_l = 0.f, st_d = 0.f;
-  auto stage_load = [&](int qb) {
+  // two register stages (tile written at the bottom of step t was requested two steps earlier): a 32-query step
+  // is ~28 MFMAs per wave, far shorter than a gathered-row fetch, and only 2 workgroups fit a CU
+  struct Stage { uint4 v[NLD]; float l, d; };
+  Stage stA, stB;
+  stA.l = stA.d = stB.l = stB.d = 0.f;
+  auto stage_load = [&](Stage& st, int qb) {
+    uint4 (&stage)[NLD] = st.v; float& st_l = st.l; float& st_d = st.d;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       int c = i * FA_THREADS + tid;
@@ -484,8 +514,8 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
         int cc = second ? c - FA_BQ2 * A::CH : c;
         int r = cc / A::CH, ch = cc - r * A::CH;
         if (qb + r < L) {
-          if (!second) v = ld16(qkv + (int64_t)gidx[p0 + qb + r] * C3 + h * D + ch * 8);
-          else { int32_t sr = sidx[p0 + qb + r]; if (sr >= 0) v = ld16(dout + (int64_t)sr * C + h * D + ch * 8); }
+          if (!second) v = ld16(qkv + (int64_t)gidx_s[qb + r] * C3 + h * D + ch * 8);
+          else { int32_t sr = sidx_s[qb + r]; if (sr >= 0) v = ld16(dout + (int64_t)sr * C + h * D + ch * 8); }
         }
       }
       stage[i] = v;
@@ -496,7 +526,8 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
       st_d = ok ? delta[(int64_t)(p0 + qb + tid) * H + h] : 0.f;
     }
   };
-  auto stage_write = [&](int b) {
+  auto stage_write = [&](Stage& st, int b) {
+    uint4 (&stage)[NLD] = st.v; const float st_l = st.l, st_d = st.d;
     char* base = smem + b * BUF;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -514,15 +545,16 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
       f[tid] = st_l; f[FA_BQ2 + tid] = st_d;
     }
   };
-  stage_load(0);
-  stage_write(0);
-  __syncthreads();
   const int ntiles = (L + FA_BQ2 - 1) / FA_BQ2;
-  for (int t = 0; t < ntiles; ++t) {
+  stage_load(stA, 0);
+  stage_write(stA, 0);
+  if (ntiles > 1) stage_load(stA, FA_BQ2);
+  if (ntiles > 2) stage_load(stB, 2 * FA_BQ2);
+  __syncthreads();
+  auto step = [&](const int t, Stage& st) {                  // st holds tile t+1
     const int b = t & 1;
     const char* Qr = smem + b * BUF; const char* Gr = Qr + RIMG; const char* Qt = Qr + 2 * RIMG; const char* Gt = Qt + TIMG;
     const float* fl = reinterpret_cast<const float*>(Qr + 2 * RIMG + 2 * TIMG);
-    if (t + 1 < ntiles) stage_load((t + 1) * FA_BQ2);
     // S[q][key], dP[q][key]: rows = queries 16qt + 4g + r, col = key lq (tile kt)
     f32x4_t s[2][FA_NT], dp[2][FA_NT];
 #pragma unroll
@@ -570,8 +602,13 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
         }
       }
     }
-    if (t + 1 < ntiles) stage_write(b ^ 1);
+    if (t + 1 < ntiles) stage_write(st, b ^ 1);
+    if (t + 3 < ntiles) stage_load(st, (t + 3) * FA_BQ2);
     __syncthreads();
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    step(t, stA);
+    if (t + 1 < ntiles) step(t + 1, stB);
   }
 #pragma unroll
   for (int kt = 0; kt < FA_NT; ++kt) {
@@ -601,7 +638,7 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
 int ss_attn_fwd_mfma(const void* qkv, const int32_t* gidx, const int32_t* sidx, const int32_t* win_start, int W,
                      int max_window, void* out, float* lse, int C, int H, float scale, hipStream_t st) {
   const int D = C / H;
-  if ((C & 7) || max_window <= 0) return SS_ERR_ARG;
+  if ((C & 7) || max_window <= 0 || max_window > FA_IDX_CAP) return SS_ERR_ARG;
   const int qchunks = (max_window + FA_BQ - 1) / FA_BQ;
   dim3 g((unsigned)(W * H * qchunks)), b(FA_THREADS);
   const unsigned short* q = (const unsigned short*)qkv; unsigned short* o = (unsigned short*)out;
@@ -619,7 +656,7 @@ int ss_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const 
                      const int32_t* sidx, const int32_t* win_start, int W, int max_window, void* dqkv, void* extra,
                      int C, int H, float scale, hipStream_t st) {
   const int D = C / H;
-  if ((C & 7) || max_window <= 0) return SS_ERR_ARG;
+  if ((C & 7) || max_window <= 0 || max_window > FA_IDX_CAP) return SS_ERR_ARG;
   const int chunks = (max_window + FA_BQ - 1) / FA_BQ;
   dim3 g((unsigned)(W * H * chunks)), b(FA_THREADS);
   const unsigned short* q = (const unsigned short*)qkv; const unsigned short* go = (const unsigned short*)dout;
