@@ -235,35 +235,52 @@ k_subm_gemm(const unsigned short* __restrict__ in, const unsigned short* __restr
   }
 }
 
-// active 64-site blocks per tap (in rowperm order): blk_list[t][0 .. blk_count[t])
-__global__ void k_subm_block_lists(const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowperm, int n, int nblocks,
-                                   int32_t* __restrict__ blk_count, int32_t* __restrict__ blk_list) {
-  __shared__ int flags_s[4];
-  __shared__ int cnt_s;
-  const int t = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (threadIdx.x == 0) cnt_s = 0;
+// active 64-site blocks per tap (in rowperm order): blk_list[t][0 .. blk_count[t]).
+// Two launches: one wave per (tap, block) writes a 0/1 flag INTO blk_list, then one workgroup per tap compacts its
+// row in place (1024 flags per round; a round reads its flags before anything is written, and writes land at
+// positions <= the round's first flag).
+__global__ void k_subm_block_flags(const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowperm, int n, int nblocks,
+                                   int32_t* __restrict__ blk_list) {
+  const int t = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int blk = blockIdx.x * 4 + wave;
+  if (blk >= nblocks) return;
+  const int k = blk * 64 + lane;
+  int j = -1;
+  if (k < n) j = nbr[(int64_t)t * n + (rowperm ? rowperm[k] : k)];
+  unsigned long long m = __ballot(j >= 0);
+  if (lane == 0) blk_list[(int64_t)t * nblocks + blk] = m != 0ULL;
+}
+
+__global__ void __launch_bounds__(1024) k_subm_block_compact(int nblocks, int32_t* __restrict__ blk_count,
+                                                              int32_t* __restrict__ blk_list) {
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  int32_t* row = blk_list + (int64_t)blockIdx.x * nblocks;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) base_s = 0;
   __syncthreads();
-  for (int base = 0; base < nblocks; base += 4) {
-    int blk = base + wave, k = blk * 64 + lane;
-    int j = -1;
-    if (blk < nblocks && k < n) j = nbr[(int64_t)t * n + (rowperm ? rowperm[k] : k)];
-    unsigned long long m = __ballot(j >= 0);
-    if (lane == 0) flags_s[wave] = m != 0ULL;
+  for (int c0 = 0; c0 < nblocks; c0 += 1024) {
+    const int b = c0 + tid;
+    const int f = b < nblocks ? row[b] : 0;
+    unsigned long long m = __ballot(f != 0);
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();                          // every flag of this round is in registers
+    int before = base_s;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (f) row[before + __popcll(m & ((1ULL << lane) - 1ULL))] = b;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      int c = cnt_s;
-      for (int w = 0; w < 4; ++w) if (flags_s[w]) blk_list[(int64_t)t * nblocks + c++] = base + w;
-      cnt_s = c;
-    }
+    if (tid == 0) { int s = 0; for (int w = 0; w < 16; ++w) s += wsum[w]; base_s += s; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) blk_count[t] = cnt_s;
+  if (tid == 0) blk_count[blockIdx.x] = base_s;
 }
 
 extern "C" int ss_subm_block_lists(const int32_t* nbr, const int32_t* rowperm, int64_t n, int taps, int32_t* blk_count,
                                    int32_t* blk_list, hipStream_t stream) {
   if (n <= 0 || taps <= 0 || n >= (1LL << 31)) return SS_ERR_ARG;
-  SS_LAUNCH(k_subm_block_lists, dim3(taps), dim3(256), 0, stream, nbr, rowperm, (int)n, ss_div_up(n, 64), blk_count, blk_list);
+  const int nblocks = ss_div_up(n, 64);
+  SS_LAUNCH(k_subm_block_flags, dim3(ss_div_up(nblocks, 4), taps), dim3(256), 0, stream, nbr, rowperm, (int)n, nblocks, blk_list);
+  SS_LAUNCH(k_subm_block_compact, dim3(taps), dim3(1024), 0, stream, nblocks, blk_count, blk_list);
   return SS_OK;
 }
 
@@ -293,7 +310,7 @@ k_subm_wgrad(const unsigned short* __restrict__ in, const unsigned short* __rest
   if (nblk <= 0) return;
   const int32_t* list = blk_list + (int64_t)tap * nblocks_total + beg;
   // plain [site][cols] image, 16-byte chunks XOR-swizzled inside each group of 16 for conflict-free transposed reads
-  auto img_off = [](int row, int ch, int rb) { return row * rb + ((((ch & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3))) | (ch & ~15)) << 4); };
+  auto img_off = [](int row, int ch, int rb) { return row * rb + ((((ch & 15) ^ ((row & 7) << 1)) | (ch & ~15)) << 4); };
   f32x4_t acc[TM][TN];
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi)

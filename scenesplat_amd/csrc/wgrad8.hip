@@ -9,8 +9,10 @@
 //
 // Both operands are [site][channel]-major, i.e. K-strided for the MFMA.  The LDS images stay plain [site][256 B]
 // rows -- what LDS-DMA writes, 4 site rows per 1-KiB wave instruction -- and the fragments are read with
-// ds_read_b64_tr_b16 (the same k permutation on both operands).  The 16-byte chunk index is XOR-swizzled per row
-// (applied to the DMA SOURCE column, and again on the read) so the transposed reads are conflict-free.
+// ds_read_b64_tr_b16 (the same k permutation on both operands).  The 16-byte chunk index is XOR-swizzled per row,
+// chunk ^= (row & 7) << 1 (applied to the DMA SOURCE column, and again on the read): a transposed read is served in
+// two 32-lane groups of 8 rows x 32 B, and the 8 rows must fall on 8 different 32-byte bank segments
+// (SQ_LDS_BANK_CONFLICT went from 48 % of the LDS cycles to 0).
 // Pipeline, phases, staggered wave rows and hazard rules: exactly gemm8.hip's (see its header).
 // GATHER: the (site, neighbour) ids of up to W8_CHUNK K-tiles live in LDS; longer shares are walked chunk by chunk.
 #include "common.h"
@@ -89,7 +91,7 @@ k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict_
 
   // ---- staging: wave-instruction (j, wave) fills site rows (j*8+wave)*4 + (lane>>4), 16-byte slot lane&15 ----
   const int srow = wave * 4 + (lane >> 4);                         // + 32 j
-  const int ssw = ((lane >> 4) << 2) | (wave & 3);                 // swizzle of those rows (same for j = 0, 1)
+  const int ssw = ((srow & 7) << 1);                               // swizzle of those rows (same for j = 0, 1)
   const int lch = (lane & 15) ^ ssw;                               // logical chunk held by the slot
   int colA[2], colB[2];
 #pragma unroll
@@ -134,7 +136,7 @@ k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict_
   };
 
   // ---- fragment reads: k rows 32kk + 4g + (lq>>2) (+16), 16-column group -> chunks 2i, 2i+1; swizzle is per lane ----
-  const int rsw = (((lq >> 2) & 3) << 2) | g;
+  const int rsw = ((4 * (g & 1) + (lq >> 2)) << 1);                // (row & 7) << 1
   const int rbase = (4 * g + (lq >> 2)) * 256 + 8 * (lq & 1);
   int oA[4], oB[2];
 #pragma unroll

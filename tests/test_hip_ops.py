@@ -139,6 +139,38 @@ def test_subm_conv_fused_mfma_against_oracle(k, cin, cout, dup):
     assert rel(bg.grad, bo.grad) < 2e-3
 
 
+@pytest.mark.parametrize("n_pts,order", [(3000, "z"), (70000, "mask"), (70000, "z")])
+def test_subm_block_lists_and_row_order(n_pts, order, monkeypatch):
+    """Active 64-site block lists (ss_subm_block_lists) against a numpy restatement, for the plain curve walk and the
+    neighbour-mask regrouped walk; the walk order must be a permutation of the sites."""
+    from scenesplat_amd import native as nv, plan as P
+    monkeypatch.setattr(P, "CONV_ORDER", order)
+    monkeypatch.setattr(P, "CONV_MASK_MIN_SITES", 1000)
+    g = torch.Generator().manual_seed(n_pts)
+    gc = torch.unique(torch.cat([torch.randint(0, 96, (n_pts, 2), generator=g), torch.randint(0, 3, (n_pts, 1), generator=g)], 1), dim=0)
+    gc = gc[torch.randperm(len(gc), generator=g)]
+    n = len(gc)
+    plan = P.build_plan(gc.cuda(), torch.tensor([n]).cuda(), ORD, ())
+    lv = plan.levels[0]
+    nbr = lv.neighbors(3); perm = lv.conv_rowperm()
+    assert sorted(perm.cpu().tolist()) == list(range(n))
+    cnt, lst = nv.subm_block_lists(nbr, perm)
+    a = (nbr[:, perm.long()] >= 0).cpu().numpy()
+    nb = (n + 63) // 64
+    a = np.concatenate([a, np.zeros((27, nb * 64 - n), bool)], 1).reshape(27, nb, 64).any(2)
+    assert cnt.cpu().tolist() == a.sum(1).tolist()
+    for t in range(27):
+        assert lst[t, :int(cnt[t])].cpu().tolist() == np.nonzero(a[t])[0].tolist()
+    if order == "mask":      # regrouping must not issue more tap work per 256-site tile than the plain walk
+        zperm = lv.order[list(lv.curve_names).index("z")]
+        def issued(p):
+            b = (nbr[:, p.long()] >= 0).cpu().numpy()
+            nt = (n + 255) // 256
+            b = np.concatenate([b, np.zeros((27, nt * 256 - n), bool)], 1).reshape(27, nt, 256).any(2)
+            return int(b.sum())
+        assert issued(perm) <= issued(zperm)
+
+
 @pytest.mark.parametrize("k,cin,cout,dup,f32out", [(3, 64, 256, False, False), (3, 128, 72, False, True), (5, 64, 48, False, False),
                                                     (3, 192, 260, True, False)])
 def test_subm_conv_pipeline_kernel_against_oracle(k, cin, cout, dup, f32out):
