@@ -306,7 +306,11 @@ extern "C" int ss_linear_wgrad(const void* x, const void* dy, float* dweight, fl
   const int tm = ss_div_up(n_out, 256), tn = ss_div_up(k_in, 256);
   static int env_per = -2;
   if (env_per == -2) { const char* e = getenv("SS_WGRAD_MINPER"); env_per = e ? atoi(e) : -1; }
-  int min_per = env_per > 0 ? env_per : w8_min_per((int64_t)tm * tn, nblocks);
+  // every block is active here, so the shares are exact: one round of <= 256 workgroups (one per CU), shares of at
+  // least 8 K-tiles (270 workgroups on 256 CUs ran two rounds: qkv 768->2304 took 622 us, 243 workgroups 440 us)
+  int min_per = env_per > 0 ? env_per : (int)(((int64_t)nblocks * tm * tn + 255) / 256);
+  if (env_per <= 0 && min_per < 8) min_per = 8;
+  if (min_per > nblocks) min_per = nblocks;
   int splits = ss_div_up(nblocks, min_per);
   dim3 g(tm * tn, 1, splits);
   SS_LAUNCH((k_wgrad8<false>), g, dim3(512), 0, stream, (const unsigned short*)x, (const unsigned short*)dy,
