@@ -54,39 +54,52 @@ def event_time_ms(fn, iters, warmup=2):
 
 
 def roofline_probes(model, data, impl):
-    """Isolated launches of the two kernels the north star prices, at the dec0 shapes of the
-    workload, timed with HIP events on the launch stream."""
+    """Isolated launches of the kernels the north star prices, at the dec0 shapes of the workload, timed with HIP
+    events on the launch stream: the dominant kernel (submanifold conv forward / dgrad on the LDS-DMA pipeline,
+    MFMA-bound), the window attention forward (MFMA / VALU-bound) and the row gather (HBM-bound)."""
     from scenesplat_amd import native as nv
     from scenesplat_amd.plan import build_plan
     plan = build_plan(data["grid_coord"], data["offset"], model.order, model.stride)
     lv = plan.levels[0]
     C, H, K = 768, 16, 1024
-    win = lv.window(0, K)
     g = torch.Generator(device="cuda").manual_seed(0)
+    pmc = {}
+    try:
+        # HBM-side bytes per launch at this shape, from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, gfx950 correction applied; scripts/gpu_pmc.sh)
+        if lv.n == 102400:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+    except Exception:
+        pass
+    # --- dominant kernel: k_gemm8<true> (CPE conv of the dec0 blocks: 4 launches per step fwd + dgrad)
+    nbr, perm = lv.neighbors(3), lv.conv_rowperm()
+    x = torch.randn(lv.n, C, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(C, 27, C, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    pairs = int((nbr >= 0).sum().item())
+    ms_c = event_time_ms(lambda: nv.subm_conv_fwd(x, w, None, nbr, perm), 5)
+    flops_c = 2.0 * pairs * C * C
+    conv = dict(bound="mfma", kernel="k_gemm8<true> subm conv fwd (dec0: n=%d, C=%d, 27 taps, %.2f pairs/site)" % (lv.n, C, pairs / lv.n),
+                achieved=flops_c / (ms_c * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
+                frac=flops_c / (ms_c * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
+                traffic=pmc.get("k_gemm8<true>@dec0", {}).get("traffic_bytes_corrected"), traffic_unit="bytes/launch beyond L2 (PMC)",
+                algorithmic_flops=flops_c, algorithmic_bytes=lv.n * C * 2 * 2 + 27 * C * C * 2, ms=ms_c)
+    # --- window attention forward
+    win = lv.window(0, K)
     qkv = torch.randn(lv.n, 3 * C, device="cuda", generator=g).to(torch.bfloat16)
     ms = event_time_ms(lambda: nv.window_attn_fwd(qkv, win, H, (C // H) ** -0.5, impl), 5)
     flops = sum(4.0 * L * L * (C // H) for L in [K] * win.num_windows) * H
-    # HBM-side bytes per launch of this kernel at this shape, from the committed PMC passes
-    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 correction applied; scripts/gpu_pmc.sh)
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if lv.n == 102400:
-            traffic = pmc["k_attn_fwd_mfma<48>@dec0"]["traffic_bytes_corrected"]
-    except Exception:
-        pass
     attn = dict(bound="mfma", kernel="k_attn_fwd_mfma<48> (dec0: %d windows x %d heads, K=%d, d=%d)" % (win.num_windows, H, K, C // H),
                 achieved=flops / (ms * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
-                frac=flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, traffic=traffic, traffic_unit="bytes/launch (PMC)",
+                frac=flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
+                traffic=pmc.get("k_attn_fwd_mfma<48>@dec0", {}).get("traffic_bytes_corrected"), traffic_unit="bytes/launch (PMC)",
                 algorithmic_flops=flops, ms=ms)
-    x = torch.randn(lv.n, C, device="cuda", generator=g).to(torch.bfloat16)
     idx = lv.order_row(0)
     out = torch.empty_like(x)
     ms2 = event_time_ms(lambda: nv.gather_rows(x, idx, out=out), 20)
     nbytes = lv.n * (2 * C * 2 + 4)
     hbm = dict(bound="hbm", kernel="gather_rows(%d x %d bf16)" % (lv.n, C), achieved=nbytes / (ms2 * 1e-3) / 1e9,
                peak=HBM_PEAK_GBS, unit="GB/s", frac=nbytes / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, ms=ms2)
-    return attn, hbm
+    return conv, attn, hbm
 
 
 def cpu_baseline(n_side):
@@ -206,9 +219,10 @@ def main():
         }
         log("timed %d steps: %.1f ms/step" % (args.steps, dt / args.steps * 1e3))
         if world == 1:
-            attn, hbm = roofline_probes(model, data, impl)
+            conv, attn, hbm = roofline_probes(model, data, impl)
             log("roofline probes done")
-            res["roofline"] = attn
+            res["roofline"] = conv
+            res["roofline_attn"] = attn
             res["roofline_hbm"] = hbm
             if not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(args.cpu_n_side)

@@ -445,7 +445,9 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
 // the lane); 32-query tiles of Q and dO stream through LDS (row image for S / dP, tr image for
 // dV^T += dO^T P and dK^T += Q^T dS).
 // =====================================================================================
-#define FA_BQ2 32
+#ifndef FA_BQ2
+#define FA_BQ2 64     // queries per step: two 32-query halves between barriers
+#endif
 template <int D>
 __global__ void __launch_bounds__(FA_THREADS)
 k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ dout,
@@ -555,7 +557,10 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
     const int b = t & 1;
     const char* Qr = smem + b * BUF; const char* Gr = Qr + RIMG; const char* Qt = Qr + 2 * RIMG; const char* Gt = Qt + TIMG;
     const float* fl = reinterpret_cast<const float*>(Qr + 2 * RIMG + 2 * TIMG);
-    // S[q][key], dP[q][key]: rows = queries 16qt + 4g + r, col = key lq (tile kt)
+#pragma unroll
+    for (int hq = 0; hq < FA_BQ2 / 32; ++hq) {
+    const char* Qr_h = Qr + hq * 32 * A::ROWB; const char* Gr_h = Gr + hq * 32 * A::ROWB;
+    // S[q][key], dP[q][key]: rows = queries 32hq + 16qt + 4g + r, col = key lq (tile kt)
     f32x4_t s[2][FA_NT], dp[2][FA_NT];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -564,7 +569,7 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
 #pragma unroll
       for (int ks = 0; ks < A::NKS; ++ks) {
         int off = row_img_off<D>(16 * qt + lq, 4 * ks + g);
-        bf8_t qa = lds_b128(Qr, off), ga = lds_b128(Gr, off);
+        bf8_t qa = lds_b128(Qr_h, off), ga = lds_b128(Gr_h, off);
 #pragma unroll
         for (int kt = 0; kt < FA_NT; ++kt) {
           s[qt][kt] = MFMA16(qa, kf[kt][ks], s[qt][kt]);
@@ -576,7 +581,7 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float l2 = fl[16 * qt + 4 * g + r], dd = fl[FA_BQ2 + 16 * qt + 4 * g + r];
+        float l2 = fl[32 * hq + 16 * qt + 4 * g + r], dd = fl[FA_BQ2 + 32 * hq + 16 * qt + 4 * g + r];
 #pragma unroll
         for (int kt = 0; kt < FA_NT; ++kt) {
           float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][kt][r], c2, -l2));
@@ -586,8 +591,8 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
       }
     // dV^T += dO^T P ; dK^T += Q^T dS ; k index (g, j) <-> query 16(j>>2) + 4g + (j&3)
     {
-      const char* gbase = Gt + (4 * g + (lq >> 2)) * A::TRB + (lq & 3) * 8;
-      const char* qbase = Qt + (4 * g + (lq >> 2)) * A::TRB + (lq & 3) * 8;
+      const char* gbase = Gt + (32 * hq + 4 * g + (lq >> 2)) * A::TRB + (lq & 3) * 8;
+      const char* qbase = Qt + (32 * hq + 4 * g + (lq >> 2)) * A::TRB + (lq & 3) * 8;
       bf8_t pf[FA_NT], df[FA_NT];
 #pragma unroll
       for (int kt = 0; kt < FA_NT; ++kt) { pf[kt] = pack8(s[0][kt], s[1][kt]); df[kt] = pack8(dp[0][kt], dp[1][kt]); }
@@ -602,6 +607,7 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
         }
       }
     }
+    }   // hq
     if (t + 1 < ntiles) stage_write(st, b ^ 1);
     if (t + 3 < ntiles) stage_load(st, (t + 3) * FA_BQ2);
     __syncthreads();

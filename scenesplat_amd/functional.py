@@ -8,6 +8,7 @@ kernels (forward and backward are separate C-ABI entry points).
   subm_conv3d        <- spconv.SubMConv3d on a cached rulebook                         (ptv3:278-284,499-506)
 """
 import torch
+from torch.utils.weak import WeakIdKeyDictionary
 
 from . import native as nv
 
@@ -136,7 +137,7 @@ class _SubMConv3dFused(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[-1]
         pad = (-cin) % 8
         x = feat.to(torch.bfloat16)
-        w = weight.reshape(cout, taps, cin).to(torch.bfloat16)
+        w = bf16_of(weight).reshape(cout, taps, cin)
         if pad:
             x = torch.nn.functional.pad(x, (0, pad)); w = torch.nn.functional.pad(w, (0, pad))
         x, w = x.contiguous(), w.contiguous()
@@ -181,6 +182,42 @@ def subm_conv3d(feat, weight, bias, nbr, has_dup=False, compute_dtype=torch.floa
     return _SubMConv3d.apply(feat, weight, bias, nbr, has_dup, compute_dtype)
 
 
+# ---- bf16 shadows of fp32 parameters ------------------------------------------------------------------
+# torch autocast casts every fp32 weight / bias with its own ~4 us kernel (PT-v3m1: ~250 launches per step).  A model
+# can register its GEMM operands here and refresh ALL shadows with a few multi-tensor copies at the start of forward.
+_SHADOW = WeakIdKeyDictionary()          # keyed by identity (Tensor.__eq__ is elementwise)
+
+
+def register_shadows(params):
+    """-> (sources, shadows) lists for refresh_shadows; idempotent per parameter."""
+    src, dst = [], []
+    for p in params:
+        if p is None or p.dtype != torch.float32 or not p.is_cuda:
+            continue
+        sh = _SHADOW.get(p)
+        if sh is None or sh.shape != p.shape or sh.device != p.device:
+            sh = torch.empty_like(p, dtype=torch.bfloat16)
+            _SHADOW[p] = sh
+        src.append(p); dst.append(sh)
+    return src, dst
+
+
+@torch.no_grad()
+def refresh_shadows(src, dst):
+    if src:
+        torch._foreach_copy_(dst, src)
+
+
+def bf16_of(p):
+    """bf16 copy of an fp32 operand: the registered shadow (refreshed by the owning model) or a fresh cast."""
+    if p is None:
+        return None
+    if p.dtype == torch.bfloat16:
+        return p
+    sh = _SHADOW.get(p) if isinstance(p, torch.nn.Parameter) else None
+    return sh if sh is not None else p.to(torch.bfloat16)
+
+
 class _Linear(torch.autograd.Function):
     """nn.Linear under bf16 autocast.  Forward and dgrad stay on hipBLASLt (NT / NN forms run at 0.9-1.3 PFLOP/s
     there); the weight gradient dy^T x -- K = sites, 0.25-0.7 PFLOP/s in hipBLASLt's TN form -- runs on the
@@ -188,8 +225,8 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        w16 = weight.to(torch.bfloat16)
-        y = torch.nn.functional.linear(x, w16, None if bias is None else bias.to(torch.bfloat16))
+        w16 = bf16_of(weight)
+        y = torch.nn.functional.linear(x, w16, bf16_of(bias))
         ctx.save_for_backward(x, w16)
         ctx.meta = (weight.dtype, bias is not None)
         return y

@@ -16,6 +16,8 @@ were trained with:
     shuffle_orders=False (ptv3:350,408-412,614-620);
   * tail windows are topped up with points borrowed from the previous window (ptv3:145-154).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -27,7 +29,8 @@ from .registry import MODELS
 from .structure import Point
 
 # knobs of the execution (not of the model): attention kernel family and conv compute dtype
-RUNTIME = dict(attn_impl=nv.ATTN_SIMT, conv_dtype=None)  # conv_dtype None: follow the reference (fp32)
+RUNTIME = dict(attn_impl=nv.ATTN_SIMT, conv_dtype=None,  # conv_dtype None: follow the reference (fp32)
+               param_shadows=os.environ.get("SS_PARAM_SHADOWS", "1") != "0")   # bf16 weight shadows under autocast
 
 
 class PointModule(nn.Module):
@@ -343,6 +346,21 @@ class PointTransformerV3(PointModule):
             plan.ready_event.record(stream)
         return plan
 
+    def _refresh_shadows(self):
+        """bf16 copies of every Linear / SubMConv3d weight and Linear bias, refreshed with multi-tensor copies."""
+        ps = self.__dict__.get("_shadow_lists")
+        if ps is None or ps[2] != next(self.parameters()).device:
+            params = []
+            for m in self.modules():
+                if isinstance(m, nn.Linear):
+                    params += [m.weight, m.bias]
+                elif isinstance(m, SubMConv3d):
+                    params.append(m.weight)
+            src, dst = SF.register_shadows(params)
+            ps = (src, dst, next(self.parameters()).device)
+            self.__dict__["_shadow_lists"] = ps
+        SF.refresh_shadows(ps[0], ps[1])
+
     def forward(self, data_dict, perms=None):
         point = data_dict if isinstance(data_dict, Point) else Point(data_dict)
         feat = point["feat"]
@@ -359,6 +377,8 @@ class PointTransformerV3(PointModule):
             offset = point["offset"]  # derived lazily from batch
         # the fused conv consumes bf16: let each block hand the next one a bf16 copy of the residual stream
         self._want_copy = (RUNTIME["conv_dtype"] == torch.bfloat16)
+        if torch.is_autocast_enabled() and RUNTIME.get("param_shadows", True):
+            self._refresh_shadows()
         plan = point.get("plan", None)
         if plan is None:
             plan = build_plan(point["grid_coord"], offset, self.order, self.stride,
