@@ -91,6 +91,10 @@ int ss_subm_rulebook(const int32_t* grid_coord, const int32_t* batch, int64_t n,
  * transposed weight (cin,taps,cout). */
 int ss_subm_conv_fwd(const void* in, const void* weight, const float* bias, const int32_t* nbr, const int32_t* rowperm,
                      void* out, int64_t n, int cin, int cout, int taps, int out_dtype, ss_stream_t stream);
+/* im2col of a submanifold conv for small levels: dst (n, taps, row_bytes) = src rows through the rulebook, zero rows for
+ * missing neighbours; row_bytes % 16 == 0.  The conv is then one plain GEMM over K = taps * Cin (spconv's gather-GEMM,
+ * ptv3:278-284, without the per-tap loop). */
+int ss_subm_im2col(const void* src, const int32_t* nbr, void* dst, int64_t n, int taps, int64_t row_bytes, ss_stream_t stream);
 /* 256 x 256 LDS-DMA pipeline GEMM (csrc/gemm8.hip).  ss_gemm8_ok: shapes it accepts (k % 64 == 0, k <= 4096, n % 4 == 0,
  * taps <= 27).  ss_subm_conv_fwd_pipe: same contract as ss_subm_conv_fwd (which dispatches to it for wide, large levels).
  * ss_linear_fwd: out (m,n) = x (m,k) bf16 @ weight (n,k)^T bf16 + bias (n) f32 or NULL  -- torch.nn.functional.linear as

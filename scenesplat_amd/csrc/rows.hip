@@ -27,6 +27,30 @@ __global__ void k_scatter_rows(const V* __restrict__ src, const int32_t* __restr
   if (d >= 0) dst[(int64_t)d * chunks + c] = src[gid];
 }
 
+// im2col of a submanifold conv: dst[i][t][:] = src[nbr[t][i]][:] (zero row when the neighbour is missing).
+// Small levels (n <~ 8k sites) turn the conv into ONE long-K library GEMM instead of a serial 27-tap loop.
+__global__ void k_subm_im2col(const uint4* __restrict__ src, const int32_t* __restrict__ nbr, uint4* __restrict__ dst,
+                              int64_t n, int taps, int chunks) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * taps * chunks) return;
+  int64_t it = gid / chunks; int c = (int)(gid - it * chunks);
+  int64_t i = it / taps; int t = (int)(it - i * taps);
+  int32_t s = nbr[(int64_t)t * n + i];
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (s >= 0) v = src[(int64_t)s * chunks + c];
+  dst[gid] = v;
+}
+
+extern "C" int ss_subm_im2col(const void* src, const int32_t* nbr, void* dst, int64_t n, int taps, int64_t row_bytes,
+                              hipStream_t stream) {
+  if (n < 0 || taps <= 0 || row_bytes <= 0 || (row_bytes & 15) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  int chunks = (int)(row_bytes >> 4);
+  SS_LAUNCH(k_subm_im2col, dim3(ss_div_up(n * taps * chunks, 256)), dim3(256), 0, stream, (const uint4*)src, nbr, (uint4*)dst,
+            n, taps, chunks);
+  return SS_OK;
+}
+
 extern "C" int ss_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_dst, int64_t row_bytes,
                               hipStream_t stream) {
   if (n_dst < 0 || row_bytes <= 0 || (row_bytes & 1)) return SS_ERR_ARG;

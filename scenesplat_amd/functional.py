@@ -7,6 +7,8 @@ kernels (forward and backward are separate C-ABI entry points).
   unpool_add         <- parent.feat + point.feat[pooling_inverse]                      (ptv3:478)
   subm_conv3d        <- spconv.SubMConv3d on a cached rulebook                         (ptv3:278-284,499-506)
 """
+import os
+
 import torch
 from torch.utils.weak import WeakIdKeyDictionary
 
@@ -141,10 +143,18 @@ class _SubMConv3dFused(torch.autograd.Function):
         if pad:
             x = torch.nn.functional.pad(x, (0, pad)); w = torch.nn.functional.pad(w, (0, pad))
         x, w = x.contiguous(), w.contiguous()
-        out = nv.subm_conv_fwd(x, w, None if bias is None else bias.float().contiguous(), nbr, rowperm)
-        ctx.save_for_backward(x, w, nbr, rowperm)
         ctx.meta = (feat.dtype, weight.dtype, weight.shape, cin, bias is not None)
         ctx.blocks_fn, ctx.has_dup = blocks_fn, has_dup
+        ctx.im2col = (n <= CONV_IM2COL_MAX_SITES) and not has_dup
+        if ctx.im2col:
+            # small level: 26 tiles for 256 CUs and a serial 27-tap loop made the implicit-GEMM kernel latency-bound
+            # (70-90 us); neighbour rows side by side + ONE long-K library GEMM takes ~30 us
+            cols = nv.subm_im2col(x, nbr)
+            out = torch.nn.functional.linear(cols, w.view(cout, -1), bf16_of(bias))
+            ctx.save_for_backward(cols, w, nbr, rowperm)
+            return out
+        out = nv.subm_conv_fwd(x, w, None if bias is None else bias.float().contiguous(), nbr, rowperm)
+        ctx.save_for_backward(x, w, nbr, rowperm)
         return out
 
     @staticmethod
@@ -153,6 +163,17 @@ class _SubMConv3dFused(torch.autograd.Function):
         in_dtype, w_dtype, w_shape, cin, has_bias = ctx.meta
         g = dout.to(torch.bfloat16).contiguous()
         dx = dw = db = None
+        if ctx.im2col:
+            cols = x                                               # saved im2col(x): (n, taps * cin_padded)
+            taps = nbr.shape[0]
+            if ctx.needs_input_grad[0]:
+                wt = w.flip(1).permute(2, 1, 0).contiguous()      # [ci][t'][co] = w[co][T-1-t'][ci]
+                dx = torch.nn.functional.linear(nv.subm_im2col(g, nbr), wt.view(wt.shape[0], -1))[:, :cin].to(in_dtype)
+            if ctx.needs_input_grad[1]:
+                dw = _mm_f32(g.t(), cols).view(w.shape)[:, :, :cin].reshape(w_shape).to(w_dtype)
+            if has_bias and ctx.needs_input_grad[2]:
+                db = g.sum(0, dtype=torch.float32).to(w_dtype)
+            return dx, dw, db, None, None, None, None
         if ctx.needs_input_grad[0]:
             wt = w.flip(1).permute(2, 1, 0).contiguous()          # [ci][t'][co] = w[co][T-1-t'][ci]
             if not ctx.has_dup:
@@ -172,6 +193,17 @@ class _SubMConv3dFused(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             db = g.sum(0, dtype=torch.float32).to(w_dtype)
         return dx, dw, db, None, None, None, None
+
+
+CONV_IM2COL_MAX_SITES = int(os.environ.get("SS_CONV_IM2COL_MAX", "8192"))
+
+
+def _mm_f32(a, b):
+    """bf16 x bf16 -> fp32 (fp32 accumulate, no bf16 rounding of the result) where the backend has aten::mm.dtype."""
+    try:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    except (RuntimeError, NotImplementedError, TypeError):
+        return torch.mm(a, b).float()
 
 
 def subm_conv3d(feat, weight, bias, nbr, has_dup=False, compute_dtype=torch.float32, rowperm=None, blocks_fn=None):

@@ -176,6 +176,18 @@ def subm_conv_fwd(x, w, bias, nbr, rowperm, out_dtype=torch.bfloat16):
     return out
 
 
+def subm_im2col(x, nbr):
+    """x (n,c) bf16 with c % 8 == 0, nbr (taps,n) -> (n, taps*c): neighbour rows side by side, zeros where missing."""
+    n, c = x.shape
+    taps = nbr.shape[0]
+    _req(x, torch.bfloat16, "x"); _req(nbr, torch.int32, "nbr", (taps, n))
+    if c % 8:
+        raise RuntimeError("subm_im2col: channels must be a multiple of 8")
+    out = torch.empty((n, taps * c), dtype=torch.bfloat16, device=x.device)
+    check(lib().ss_subm_im2col(_p(x), _p(nbr), _p(out), n, taps, c * 2, _stream()), "ss_subm_im2col")
+    return out
+
+
 def subm_conv_fwd_pipe(x, w, bias, nbr, rowperm, out_dtype=torch.bfloat16):
     """The LDS-DMA pipeline kernel directly (tests / benches); subm_conv_fwd dispatches to it for wide, large levels."""
     n, cin = x.shape
