@@ -180,7 +180,9 @@ def main():
         state["prev"] = plan
         # backward from the seeded random cotangent, fed directly as the output gradient (no loss kernels)
         torch.autograd.backward(out.feat, grad_tensors=cot.to(out.feat.dtype))
-        state["plan"] = model.prepare_plan(data, stream=side)
+        # SS_BENCH_REUSE_PLAN=1 is a DIAGNOSTIC (host- vs GPU-bound?): it skips the per-step plan build and the line it
+        # prints is not the metric
+        state["plan"] = plan if os.environ.get("SS_BENCH_REUSE_PLAN") == "1" else model.prepare_plan(data, stream=side)
 
     def log(msg):
         if rank == 0:
@@ -211,7 +213,7 @@ def main():
             "metric": "Gaussians/s encoder fwd+bwd, 102k-pt chunks", "value": world * n * args.steps / dt,
             "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16", "data": "synthetic" if os.environ.get("SS_BENCH_REUSE_PLAN") != "1" else "synthetic, DIAGNOSTIC: plan reused (invalid as metric)",
             "config": {"workload": "room-%d: PT-v3m1 lang-pretrain encoder (91.71M params, in=11, out=768) fwd+bwd, "
                                    "1 chunk of %d Gaussians per GPU per step, serialization included" % (n, n),
                        "gaussians_per_chunk": n, "chunks_per_gpu": 1,

@@ -220,6 +220,28 @@ def subm_block_lists(nbr, rowperm):
     return cnt, lst
 
 
+# ---- zero-initialised fp32 arena for the weight-gradient accumulators -------------------------------
+# The wgrad kernels accumulate with fp32 atomics into ZEROED outputs; ~80 separate torch.zeros per backward cost
+# ~0.9 ms of fill kernels and as many launches.  A model may reserve one zero-filled block per step
+# (zero_arena_begin) from which the accumulators are carved; without a reservation each call allocates its own.
+_ARENA = {"buf": None, "off": 0}
+
+
+def zero_arena_begin(numel, device):
+    """Reserve `numel` zero-filled fp32 elements (one fill kernel) for this step's wgrad accumulators."""
+    _ARENA["buf"] = torch.zeros(int(numel), dtype=torch.float32, device=device) if numel > 0 else None
+    _ARENA["off"] = 0
+
+
+def zeros_f32(numel, device):
+    """numel zero fp32 elements: a slice of the step's arena when it has room (16-byte aligned), else a fresh tensor."""
+    buf, off = _ARENA["buf"], _ARENA["off"]
+    if buf is not None and buf.device == device and off + numel <= buf.numel():
+        _ARENA["off"] = off + ((numel + 3) & ~3)
+        return buf[off:off + numel]
+    return torch.zeros(int(numel), dtype=torch.float32, device=device)
+
+
 def subm_conv_wgrad(x, dout, nbr, rowperm, blocks):
     """-> dW (cout,taps,cin) f32 = sum_i dout[i] (x) x[nbr[t][i]].  blocks = subm_block_lists(nbr, rowperm)."""
     n, cin = x.shape
@@ -230,7 +252,7 @@ def subm_conv_wgrad(x, dout, nbr, rowperm, blocks):
         raise RuntimeError("subm_conv_wgrad: channels must be multiples of 8")
     if rowperm is not None:
         _req(rowperm, torch.int32, "rowperm", (n,))
-    dw = torch.zeros((cout, taps, cin), dtype=torch.float32, device=x.device)
+    dw = zeros_f32(cout * taps * cin, x.device).view(cout, taps, cin)
     cnt, lst = blocks
     _req(cnt, torch.int32, "blk_count", (taps,)); _req(lst, torch.int32, "blk_list", (taps, (n + 63) // 64))
     check(lib().ss_subm_conv_wgrad(_p(x), _p(dout), _p(nbr), _p(rowperm), _p(cnt), _p(lst), _p(dw), n, cin, cout, taps,
@@ -255,7 +277,7 @@ def linear_wgrad(x, dy, want_bias=False):
     m, k = x.shape
     nout = dy.shape[1]
     _req(x, torch.bfloat16, "x"); _req(dy, torch.bfloat16, "dy", (m, nout))
-    buf = torch.zeros(nout * k + (nout if want_bias else 0), dtype=torch.float32, device=x.device)
+    buf = zeros_f32(nout * k + (nout if want_bias else 0), x.device)
     dw = buf[:nout * k].view(nout, k)
     db = buf[nout * k:] if want_bias else None
     check(lib().ss_linear_wgrad(_p(x), _p(dy), _p(dw), _p(db), m, k, nout, _stream()), "ss_linear_wgrad")

@@ -357,9 +357,13 @@ class PointTransformerV3(PointModule):
                 elif isinstance(m, SubMConv3d):
                     params.append(m.weight)
             src, dst = SF.register_shadows(params)
-            ps = (src, dst, next(self.parameters()).device)
+            # fp32 accumulators of the weight / bias gradients: one zero-filled arena per step
+            total = sum(((p.numel() + 3) & ~3) for p in params if p is not None) + 4 * len(params)
+            ps = (src, dst, next(self.parameters()).device, total)
             self.__dict__["_shadow_lists"] = ps
         SF.refresh_shadows(ps[0], ps[1])
+        if torch.is_grad_enabled():
+            nv.zero_arena_begin(ps[3], ps[2])
 
     def forward(self, data_dict, perms=None):
         point = data_dict if isinstance(data_dict, Point) else Point(data_dict)
