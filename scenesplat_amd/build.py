@@ -45,7 +45,7 @@ def build(force=False, verbose=True):
                # keep MFMA accumulators in VGPRs: the softmax / epilogue VALU code consumes them directly,
                # the default AGPR form costs a v_accvgpr_read/write per element (measured: 144 of ~560
                # instructions per attention tile)
-               "-mllvm", "-amdgpu-mfma-vgpr-form"]
+               "-mllvm", "-amdgpu-mfma-vgpr-form"] + os.environ.get("SS_EXTRA_HIPCC_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

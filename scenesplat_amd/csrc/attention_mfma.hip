@@ -84,6 +84,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {   // bijective: bloc
 #define FA_WQ (16 * FA_NT)            // rows (queries / keys) per wave
 #define FA_BQ (FA_WQ * FA_WAVES)      // 256 rows per workgroup
 #define FA_BK 64
+#ifndef FA_PREFETCH2
+#define FA_PREFETCH2 0   // 1: two register stages (tile requested two steps ahead); measured neutral, costs 12-18 VGPRs
+#endif
 #define FA_IDX_CAP SS_ATTN_MFMA_MAX_WINDOW   // longest window whose gather rows fit the LDS copy (launchers refuse longer ones)
 
 // stage a 64-row K/V tile (rows gidx[p0+r0 .. +63], column block `colofs`) into registers
@@ -190,11 +193,12 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
   const int ntiles = (L + FA_BK - 1) / FA_BK;
   tile_load<D, NLD>(stA, qkv, gidx_s, 0, L, C3, C + h * D, 2 * C + h * D, tid);
   stage_write(stA, 0);
-  if (ntiles > 1) tile_load<D, NLD>(stA, qkv, gidx_s, FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
-  if (ntiles > 2) tile_load<D, NLD>(stB, qkv, gidx_s, 2 * FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
+  if (FA_PREFETCH2 && ntiles > 1) tile_load<D, NLD>(stA, qkv, gidx_s, FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
+  if (FA_PREFETCH2 && ntiles > 2) tile_load<D, NLD>(stB, qkv, gidx_s, 2 * FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
   __syncthreads();
-  auto step = [&](const int t, uint4 (&stage)[NLD]) {      // stage holds tile t+1
+  auto step = [&](const int t, uint4 (&stage)[NLD]) {      // FA_PREFETCH2: stage holds tile t+1
     const int b = t & 1, kv0 = t * FA_BK;
+    if (!FA_PREFETCH2 && t + 1 < ntiles) tile_load<D, NLD>(stage, qkv, gidx_s, kv0 + FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
     // ---- S^T = K Q^T : s[kt][qt], rows = keys 16kt + 4g + r, col = query lq
     f32x4_t s[4][FA_NT];
 #pragma unroll
@@ -262,12 +266,16 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
       }
     }
     if (t + 1 < ntiles) stage_write(stage, b ^ 1);
-    if (t + 3 < ntiles) tile_load<D, NLD>(stage, qkv, gidx_s, kv0 + 3 * FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
+    if (FA_PREFETCH2 && t + 3 < ntiles) tile_load<D, NLD>(stage, qkv, gidx_s, kv0 + 3 * FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
     __syncthreads();
   };
-  for (int t = 0; t < ntiles; t += 2) {
-    step(t, stA);
-    if (t + 1 < ntiles) step(t + 1, stB);
+  if (FA_PREFETCH2) {
+    for (int t = 0; t < ntiles; t += 2) {
+      step(t, stA);
+      if (t + 1 < ntiles) step(t + 1, stB);
+    }
+  } else {
+    for (int t = 0; t < ntiles; ++t) step(t, stA);
   }
   // ---- epilogue
 #pragma unroll
@@ -296,8 +304,11 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
 // backward, dQ: query-stationary.  S^T and dP^T = V dO^T (key rows, query on the lane),
 // dS^T = P^T o (dP^T - delta_q), dQ^T += K^T dS^T with K^T read transposed from a plain image.
 // =====================================================================================
+#ifndef FA_BWD_MIN_BLOCKS
+#define FA_BWD_MIN_BLOCKS 1   // 3 would cap the backward kernels at 168 VGPRs (3 waves / SIMD)
+#endif
 template <int D>
-__global__ void __launch_bounds__(FA_THREADS)
+__global__ void __launch_bounds__(FA_THREADS, FA_BWD_MIN_BLOCKS)
 k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ dout,
                    const float* __restrict__ lse, const float* __restrict__ delta, const int32_t* __restrict__ gidx,
                    const int32_t* __restrict__ sidx, const int32_t* __restrict__ win_start,
@@ -370,12 +381,13 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
   const int ntiles = (L + FA_BK - 1) / FA_BK;
   tile_load<D, NLD>(stA, qkv, gidx_s, 0, L, C3, C + h * D, 2 * C + h * D, tid);
   stage_write(stA, 0);
-  if (ntiles > 1) tile_load<D, NLD>(stA, qkv, gidx_s, FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
-  if (ntiles > 2) tile_load<D, NLD>(stB, qkv, gidx_s, 2 * FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
+  if (FA_PREFETCH2 && ntiles > 1) tile_load<D, NLD>(stA, qkv, gidx_s, FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
+  if (FA_PREFETCH2 && ntiles > 2) tile_load<D, NLD>(stB, qkv, gidx_s, 2 * FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
   __syncthreads();
-  auto step = [&](const int t, uint4 (&stage)[NLD]) {        // stage holds tile t+1
+  auto step = [&](const int t, uint4 (&stage)[NLD]) {        // FA_PREFETCH2: stage holds tile t+1
     const int b = t & 1, kv0 = t * FA_BK;
     const char* Kr = smem + b * BUF; const char* Vr = Kr + RIMG; const char* Kt = Kr + 2 * RIMG;
+    if (!FA_PREFETCH2 && t + 1 < ntiles) tile_load<D, NLD>(stage, qkv, gidx_s, kv0 + FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
     f32x4_t s[4][FA_NT], dp[4][FA_NT];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -418,12 +430,16 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
       }
     }
     if (t + 1 < ntiles) stage_write(stage, b ^ 1);
-    if (t + 3 < ntiles) tile_load<D, NLD>(stage, qkv, gidx_s, kv0 + 3 * FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
+    if (FA_PREFETCH2 && t + 3 < ntiles) tile_load<D, NLD>(stage, qkv, gidx_s, kv0 + 3 * FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
     __syncthreads();
   };
-  for (int t = 0; t < ntiles; t += 2) {
-    step(t, stA);
-    if (t + 1 < ntiles) step(t + 1, stB);
+  if (FA_PREFETCH2) {
+    for (int t = 0; t < ntiles; t += 2) {
+      step(t, stA);
+      if (t + 1 < ntiles) step(t + 1, stB);
+    }
+  } else {
+    for (int t = 0; t < ntiles; ++t) step(t, stA);
   }
 #pragma unroll
   for (int qt = 0; qt < FA_NT; ++qt) {
@@ -449,7 +465,7 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
 #define FA_BQ2 64     // queries per step: two 32-query halves between barriers
 #endif
 template <int D>
-__global__ void __launch_bounds__(FA_THREADS)
+__global__ void __launch_bounds__(FA_THREADS, FA_BWD_MIN_BLOCKS)
 k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ dout,
                     const float* __restrict__ lse, const float* __restrict__ delta, const int32_t* __restrict__ gidx,
                     const int32_t* __restrict__ sidx, const int32_t* __restrict__ win_start,
@@ -550,11 +566,12 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
   const int ntiles = (L + FA_BQ2 - 1) / FA_BQ2;
   stage_load(stA, 0);
   stage_write(stA, 0);
-  if (ntiles > 1) stage_load(stA, FA_BQ2);
-  if (ntiles > 2) stage_load(stB, 2 * FA_BQ2);
+  if (FA_PREFETCH2 && ntiles > 1) stage_load(stA, FA_BQ2);
+  if (FA_PREFETCH2 && ntiles > 2) stage_load(stB, 2 * FA_BQ2);
   __syncthreads();
-  auto step = [&](const int t, Stage& st) {                  // st holds tile t+1
+  auto step = [&](const int t, Stage& st) {                  // FA_PREFETCH2: st holds tile t+1
     const int b = t & 1;
+    if (!FA_PREFETCH2 && t + 1 < ntiles) stage_load(st, (t + 1) * FA_BQ2);
     const char* Qr = smem + b * BUF; const char* Gr = Qr + RIMG; const char* Qt = Qr + 2 * RIMG; const char* Gt = Qt + TIMG;
     const float* fl = reinterpret_cast<const float*>(Qr + 2 * RIMG + 2 * TIMG);
 #pragma unroll
@@ -609,12 +626,16 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
     }
     }   // hq
     if (t + 1 < ntiles) stage_write(st, b ^ 1);
-    if (t + 3 < ntiles) stage_load(st, (t + 3) * FA_BQ2);
+    if (FA_PREFETCH2 && t + 3 < ntiles) stage_load(st, (t + 3) * FA_BQ2);
     __syncthreads();
   };
-  for (int t = 0; t < ntiles; t += 2) {
-    step(t, stA);
-    if (t + 1 < ntiles) step(t + 1, stB);
+  if (FA_PREFETCH2) {
+    for (int t = 0; t < ntiles; t += 2) {
+      step(t, stA);
+      if (t + 1 < ntiles) step(t + 1, stB);
+    }
+  } else {
+    for (int t = 0; t < ntiles; ++t) step(t, stA);
   }
 #pragma unroll
   for (int kt = 0; kt < FA_NT; ++kt) {
