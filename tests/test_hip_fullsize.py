@@ -130,3 +130,40 @@ def test_million_gaussian_region_plan_and_scan():
     sub = slice(123_000, 125_000)
     ref = torch.sigmoid(feat[sub].float() @ text.float().t()).max(1)
     assert torch.allclose(mp[sub], ref.values, atol=3e-4) and (am[sub].long() == ref.indices).float().mean() > 0.995
+
+
+def test_pipeline_kernels_race_screen_and_linearity(room):
+    """The LDS-DMA pipeline kernels order their LDS traffic by counted vmcnt + barriers only, so an early read would
+    pass a reference check whenever the DMA happens to land first.  Screen: the conv forward has no atomics, so
+    repeated launches on every level must be BIT-identical; it must also be linear in x (f(a+b) = f(a) + f(b) with
+    a, b exactly representable sums), and the weight gradients (fp32 atomics, order-dependent) must agree with the
+    register-staged 128x128 kernel to accumulation noise."""
+    from scenesplat_amd import native as nv
+    data, plan = room
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for li, C in ((0, 192), (1, 256), (2, 64)):
+        lv = plan.levels[li]
+        nbr, perm, blocks = lv.neighbors(3), lv.conv_rowperm(), lv.conv_blocks(3)
+        xa = torch.randint(-4, 5, (lv.n, C), device="cuda", generator=g).to(torch.bfloat16)      # small integers:
+        xb = torch.randint(-4, 5, (lv.n, C), device="cuda", generator=g).to(torch.bfloat16)      # exact in bf16/fp32
+        w = torch.randint(-2, 3, (C, 27, C), device="cuda", generator=g).to(torch.bfloat16)
+        ya = nv.subm_conv_fwd_pipe(xa, w, None, nbr, perm, torch.float32)
+        for _ in range(8):
+            assert torch.equal(nv.subm_conv_fwd_pipe(xa, w, None, nbr, perm, torch.float32), ya)
+        yb = nv.subm_conv_fwd_pipe(xb, w, None, nbr, perm, torch.float32)
+        yab = nv.subm_conv_fwd_pipe(xa + xb, w, None, nbr, perm, torch.float32)
+        assert torch.equal(yab, ya + yb)                                        # integer-valued: exact linearity
+        go = torch.randint(-2, 3, (lv.n, C), device="cuda", generator=g).to(torch.bfloat16)
+        dw0 = nv.subm_conv_wgrad_pipe(xa, go, nbr, perm, blocks)
+        for _ in range(4):
+            assert torch.equal(nv.subm_conv_wgrad_pipe(xa, go, nbr, perm, blocks), dw0)   # integer sums: order-free
+        # independent restatement of dW[co][t][ci] = sum_i go[i][co] * xa[nbr[t][i]][ci] for three taps
+        for t in (0, 13, 26):
+            j = nbr[t].long()
+            xg = torch.where((j >= 0).unsqueeze(1), xa[j.clamp_min(0)].float(), torch.zeros((), device="cuda"))
+            assert torch.equal(dw0[:, t, :], go.float().t() @ xg)
+        dwl, dbl = nv.linear_wgrad(xa, go, True)
+        for _ in range(4):
+            d2, b2 = nv.linear_wgrad(xa, go, True)
+            assert torch.equal(d2, dwl) and torch.equal(b2, dbl)
+        assert torch.equal(dwl, go.float().t() @ xa.float()) and torch.equal(dbl, go.float().sum(0))
