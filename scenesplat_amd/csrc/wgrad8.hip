@@ -103,13 +103,22 @@ k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict_
   const unsigned short* pA[2];
   const unsigned short* pB[2];
   int chunk_beg = beg, T = 0, staged = 0;
-  auto load_rows = [&](int s) {
+  int nis[2] = {-1, -1}, njs[2] = {-1, -1};    // site / neighbour ids of the NEXT tile to stage (GATHER)
+  // read one phase early (ph4, which has no fragment reads) so ph2 only does pointer arithmetic
+  auto prefetch_idx = [&]() {
+    if (!GATHER || staged + 1 >= T) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      nis[j] = isite_s[(staged + 1) * 64 + srow + 32 * j];
+      njs[j] = jsite_s[(staged + 1) * 64 + srow + 32 * j];
+    }
+  };
+  auto make_rows = [&](int s) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (GATHER) {
-        int is = isite_s[s * 64 + srow + 32 * j], js = jsite_s[s * 64 + srow + 32 * j];
-        pA[j] = js >= 0 ? DY + (int64_t)is * Cout : zrow;
-        pB[j] = js >= 0 ? X + (int64_t)js * Cin : zrow;
+        pA[j] = njs[j] >= 0 ? DY + (int64_t)nis[j] * Cout : zrow;
+        pB[j] = njs[j] >= 0 ? X + (int64_t)njs[j] * Cin : zrow;
       } else {
         int64_t k = (int64_t)(chunk_beg + s) * 64 + srow + 32 * j;
         pA[j] = k < n ? DY + k * Cout : zrow;
@@ -120,7 +129,7 @@ k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict_
   auto advance = [&]() {
     if (staged + 1 >= T) return;
     ++staged;
-    load_rows(staged);
+    make_rows(staged);
   };
   const unsigned dst0 = __builtin_amdgcn_readfirstlane(
       (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem) + (unsigned)wave * 1024u);
@@ -188,11 +197,15 @@ k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict_
       }
       __syncthreads();
     }
+    staged = -1;
+    prefetch_idx();
     staged = 0;
-    load_rows(0);
+    make_rows(0);
+    prefetch_idx();
     // prologue: tile 0 complete + B0 A0 B1 of tile 1
     stageB(0, 0); stageA(0, 0); stageB(0, 1); stageA(0, 1);
     advance();
+    prefetch_idx();                              // tile 2, consumed by ph2 of the first iteration
     stageB(1, 0); stageA(1, 0); stageB(1, 1);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     W8_BAR();
@@ -225,6 +238,7 @@ k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict_
       W8_COMPUTE_END();
       // ph4
       stageB(buf, 1);
+      prefetch_idx();                            // ids of tile staged+1, retired by this phase's lgkmcnt(0)
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       W8_COMPUTE_BEGIN();
       W8_MM(1, 0, b0f)
