@@ -51,6 +51,16 @@ extern "C" int ss_subm_im2col(const void* src, const int32_t* nbr, void* dst, in
   return SS_OK;
 }
 
+// A HIP stream whose kernels may only use the CUs set in `mask` (bit i of word i/32 = CU i).  The deferred
+// weight-gradient launches run on such a stream (every other CU) so the latency-bound main chain always finds free CUs.
+extern "C" int ss_stream_create_cu_mask(int nwords, const uint32_t* mask, void** stream_out) {
+  if (nwords <= 0 || !mask || !stream_out) return SS_ERR_ARG;
+  hipStream_t st = nullptr;
+  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask) != hipSuccess) { (void)hipGetLastError(); return SS_ERR_LAUNCH; }
+  *stream_out = (void*)st;
+  return SS_OK;
+}
+
 extern "C" int ss_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_dst, int64_t row_bytes,
                               hipStream_t stream) {
   if (n_dst < 0 || row_bytes <= 0 || (row_bytes & 1)) return SS_ERR_ARG;

@@ -242,8 +242,9 @@ def zeros_f32(numel, device):
     return torch.zeros(int(numel), dtype=torch.float32, device=device)
 
 
-def subm_conv_wgrad(x, dout, nbr, rowperm, blocks):
-    """-> dW (cout,taps,cin) f32 = sum_i dout[i] (x) x[nbr[t][i]].  blocks = subm_block_lists(nbr, rowperm)."""
+def subm_conv_wgrad(x, dout, nbr, rowperm, blocks, out=None):
+    """-> dW (cout,taps,cin) f32 = sum_i dout[i] (x) x[nbr[t][i]].  blocks = subm_block_lists(nbr, rowperm).
+    out: a ZEROED (cout,taps,cin) f32 accumulator to add into (deferred launches)."""
     n, cin = x.shape
     cout = dout.shape[1]
     taps = nbr.shape[0]
@@ -252,7 +253,7 @@ def subm_conv_wgrad(x, dout, nbr, rowperm, blocks):
         raise RuntimeError("subm_conv_wgrad: channels must be multiples of 8")
     if rowperm is not None:
         _req(rowperm, torch.int32, "rowperm", (n,))
-    dw = zeros_f32(cout * taps * cin, x.device).view(cout, taps, cin)
+    dw = zeros_f32(cout * taps * cin, x.device).view(cout, taps, cin) if out is None else _req(out, torch.float32, "out", (cout, taps, cin))
     cnt, lst = blocks
     _req(cnt, torch.int32, "blk_count", (taps,)); _req(lst, torch.int32, "blk_list", (taps, (n + 63) // 64))
     check(lib().ss_subm_conv_wgrad(_p(x), _p(dout), _p(nbr), _p(rowperm), _p(cnt), _p(lst), _p(dw), n, cin, cout, taps,
@@ -269,6 +270,20 @@ def subm_conv_wgrad_pipe(x, dout, nbr, rowperm, blocks):
     check(lib().ss_subm_conv_wgrad_pipe(_p(x), _p(dout), _p(nbr), _p(rowperm), _p(cnt), _p(lst), _p(dw), n, cin, cout, taps,
                                         _stream()), "ss_subm_conv_wgrad_pipe")
     return dw
+
+
+def linear_wgrad_alloc(k, nout, want_bias, device):
+    """Zeroed fp32 accumulators (dW (nout,k), db (nout) | None) sharing one allocation."""
+    buf = zeros_f32(nout * k + (nout if want_bias else 0), device)
+    return buf[:nout * k].view(nout, k), (buf[nout * k:] if want_bias else None)
+
+
+def linear_wgrad_into(x, dy, dw, db):
+    """dw += dy^T @ x, db += column sums of dy (db may be None); dw / db must be zero on the first call."""
+    m, k = x.shape
+    nout = dy.shape[1]
+    _req(x, torch.bfloat16, "x"); _req(dy, torch.bfloat16, "dy", (m, nout)); _req(dw, torch.float32, "dw", (nout, k))
+    check(lib().ss_linear_wgrad(_p(x), _p(dy), _p(dw), _p(db), m, k, nout, _stream()), "ss_linear_wgrad")
 
 
 def linear_wgrad(x, dy, want_bias=False):

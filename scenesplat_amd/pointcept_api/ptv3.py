@@ -407,11 +407,15 @@ class PointTransformerV3(PointModule):
             for s in reversed(range(self.num_stages - 1)):
                 dec = getattr(self.dec, f"dec{s}")
                 x, conv_in = dec.up(x, skips[s], levels[s + 1])
+                if s == 0 and self.training:
+                    x = SF.defer_marker(x)       # backward leaves the full-resolution stage here: launch its queued wgrads
                 xb = None
                 for i in range(self.dec_depths[s]):
                     x, xb = getattr(dec, f"block{i}")(x, conv_in if i == 0 else (x if xb is None else xb), levels[s],
                                                       self._want_copy and i + 1 < self.dec_depths[s])
             lv = 0
+            if self.training:
+                SF.defer_open()                  # backward starts in dec0: queue its weight gradients (see SF._Defer)
         out = Point(feat=x, plan=plan, level=lv)
         for k in ("coord", "grid_coord", "offset"):
             if lv == 0 and dict.__contains__(point, k):

@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""A/B of a runtime switch inside ONE process (interleaved blocks; run-to-run noise of separate processes is +-2 ms):
+   python scripts/ab_step.py defer|shadows|im2col|arena [blocks] [steps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from scenesplat_amd import native as nv, functional as SF
+from scenesplat_amd.pointcept_api import MODELS, RUNTIME
+from scenesplat_amd.synthetic import LANG_PTV3, room_chunk
+
+which = sys.argv[1] if len(sys.argv) > 1 else "defer"
+blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+RUNTIME["attn_impl"] = nv.ATTN_MFMA; RUNTIME["conv_dtype"] = torch.bfloat16
+model = MODELS.build(dict(type="PT-v3m1", **LANG_PTV3)).cuda().train()
+data = {k: v.cuda() for k, v in room_chunk(256, 0, lang_dim=0).items()}
+cot = torch.randn(len(data["feat"]), 768, device="cuda").to(torch.bfloat16)
+side = torch.cuda.Stream()
+state = {"plan": model.prepare_plan(data, stream=side)}
+
+
+def setter(on):
+    if which == "defer":
+        SF._Defer.enabled = on
+    elif which == "shadows":
+        RUNTIME["param_shadows"] = on
+    elif which == "im2col":
+        SF.CONV_IM2COL_MAX_SITES = 8192 if on else 0
+    elif which == "wgrad_rows":
+        SF.LINEAR_WGRAD_MIN_ROWS = 256 if on else 1024
+    elif which == "im2col_big":
+        SF.CONV_IM2COL_MAX_SITES = 32768 if on else 8192
+    elif which == "mask_small":
+        import scenesplat_amd.plan as P
+        P.CONV_MASK_MIN_SITES = 4096 if on else 16384
+    else:
+        raise SystemExit("unknown switch")
+
+
+def step():
+    model.zero_grad(set_to_none=True)
+    plan, state["plan"] = state["plan"], None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(dict(feat=data["feat"], grid_coord=data["grid_coord"], offset=data["offset"], plan=plan))
+    state["prev"] = plan
+    torch.autograd.backward(out.feat, grad_tensors=cot.to(out.feat.dtype))
+    state["plan"] = model.prepare_plan(data, stream=side)
+
+
+for on in (True, False):
+    setter(on)
+    for _ in range(3):
+        step()
+torch.cuda.synchronize()
+res = {True: [], False: []}
+for b in range(blocks):
+    on = (b % 2 == 0)
+    setter(on)
+    step(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    res[on].append((time.perf_counter() - t0) / steps * 1e3)
+print(which, "ON ", " ".join(f"{v:.1f}" for v in res[True]), " mean %.2f" % (sum(res[True]) / len(res[True])))
+print(which, "OFF", " ".join(f"{v:.1f}" for v in res[False]), " mean %.2f" % (sum(res[False]) / len(res[False])))
