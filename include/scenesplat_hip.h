@@ -91,6 +91,8 @@ int ss_subm_rulebook(const int32_t* grid_coord, const int32_t* batch, int64_t n,
  * transposed weight (cin,taps,cout). */
 int ss_subm_conv_fwd(const void* in, const void* weight, const float* bias, const int32_t* nbr, const int32_t* rowperm,
                      void* out, int64_t n, int cin, int cout, int taps, int out_dtype, ss_stream_t stream);
+/* bf16 weight of the dgrad pass: wt (cin, taps, cout)[ci][T-1-t][co] = w (cout, taps, cin)[co][t][ci] */
+int ss_subm_weight_mirror(const void* w, void* wt, int cout, int taps, int cin, ss_stream_t stream);
 /* stream restricted to the CUs set in mask (hipExtStreamCreateWithCUMask); used for the deferred weight gradients */
 int ss_stream_create_cu_mask(int nwords, const uint32_t* mask, void** stream_out);
 /* im2col of a submanifold conv for small levels: dst (n, taps, row_bytes) = src rows through the rulebook, zero rows for

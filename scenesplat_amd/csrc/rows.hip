@@ -27,6 +27,33 @@ __global__ void k_scatter_rows(const V* __restrict__ src, const int32_t* __restr
   if (d >= 0) dst[(int64_t)d * chunks + c] = src[gid];
 }
 
+// dgrad weight of a submanifold conv: wt[ci][T-1-t][co] = w[co][t][ci] (tap-mirrored transpose, bf16), one pass through
+// 32 x 32 LDS tiles so both the reads (ci fastest) and the writes (co fastest) are coalesced.
+__global__ void k_subm_weight_mirror(const unsigned short* __restrict__ w, unsigned short* __restrict__ wt, int cout, int taps,
+                                     int cin) {
+  __shared__ unsigned short tile[32][33];
+  const int t = blockIdx.z, co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 256 threads: 8 rows per pass
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < cout && ci < cin) ? w[((int64_t)co * taps + t) * cin + ci] : (unsigned short)0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    int ci = ci0 + r, co = co0 + tx;
+    if (ci < cin && co < cout) wt[((int64_t)ci * taps + (taps - 1 - t)) * cout + co] = tile[tx][r];
+  }
+}
+
+extern "C" int ss_subm_weight_mirror(const void* w, void* wt, int cout, int taps, int cin, hipStream_t stream) {
+  if (cout <= 0 || taps <= 0 || cin <= 0 || taps > 65535) return SS_ERR_ARG;
+  SS_LAUNCH(k_subm_weight_mirror, dim3(ss_div_up(cin, 32), ss_div_up(cout, 32), taps), dim3(256), 0, stream,
+            (const unsigned short*)w, (unsigned short*)wt, cout, taps, cin);
+  return SS_OK;
+}
+
 // im2col of a submanifold conv: dst[i][t][:] = src[nbr[t][i]][:] (zero row when the neighbour is missing).
 // Small levels (n <~ 8k sites) turn the conv into ONE long-K library GEMM instead of a serial 27-tap loop.
 __global__ void k_subm_im2col(const uint4* __restrict__ src, const int32_t* __restrict__ nbr, uint4* __restrict__ dst,

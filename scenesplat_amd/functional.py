@@ -167,7 +167,7 @@ class _SubMConv3dFused(torch.autograd.Function):
             cols = x                                               # saved im2col(x): (n, taps * cin_padded)
             taps = nbr.shape[0]
             if ctx.needs_input_grad[0]:
-                wt = w.flip(1).permute(2, 1, 0).contiguous()      # [ci][t'][co] = w[co][T-1-t'][ci]
+                wt = nv.subm_weight_mirror(w)                          # [ci][t'][co] = w[co][T-1-t'][ci]
                 dx = torch.nn.functional.linear(nv.subm_im2col(g, nbr), wt.view(wt.shape[0], -1))[:, :cin].to(in_dtype)
             if ctx.needs_input_grad[1]:
                 dw = _mm_f32(g.t(), cols).view(w.shape)[:, :, :cin].reshape(w_shape).to(w_dtype)
@@ -175,7 +175,7 @@ class _SubMConv3dFused(torch.autograd.Function):
                 db = g.sum(0, dtype=torch.float32).to(w_dtype)
             return dx, dw, db, None, None, None, None
         if ctx.needs_input_grad[0]:
-            wt = w.flip(1).permute(2, 1, 0).contiguous()          # [ci][t'][co] = w[co][T-1-t'][ci]
+            wt = nv.subm_weight_mirror(w)                              # [ci][t'][co] = w[co][T-1-t'][ci]
             if not ctx.has_dup:
                 dx = nv.subm_conv_fwd(g, wt, None, nbr, rowperm)[:, :cin].to(in_dtype)
             else:

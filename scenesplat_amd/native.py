@@ -176,6 +176,15 @@ def subm_conv_fwd(x, w, bias, nbr, rowperm, out_dtype=torch.bfloat16):
     return out
 
 
+def subm_weight_mirror(w):
+    """w (cout,taps,cin) bf16 -> wt (cin,taps,cout) bf16 with wt[ci][T-1-t][co] = w[co][t][ci] (dgrad weight)."""
+    cout, taps, cin = w.shape
+    _req(w, torch.bfloat16, "w")
+    wt = torch.empty((cin, taps, cout), dtype=torch.bfloat16, device=w.device)
+    check(lib().ss_subm_weight_mirror(_p(w), _p(wt), cout, taps, cin, _stream()), "ss_subm_weight_mirror")
+    return wt
+
+
 def subm_im2col(x, nbr):
     """x (n,c) bf16 with c % 8 == 0, nbr (taps,n) -> (n, taps*c): neighbour rows side by side, zeros where missing."""
     n, c = x.shape

@@ -30,6 +30,12 @@ def setter(on):
         SF.LINEAR_WGRAD_MIN_ROWS = 256 if on else 1024
     elif which == "im2col_big":
         SF.CONV_IM2COL_MAX_SITES = 32768 if on else 8192
+    elif which == "coarse15":
+        import scenesplat_amd.plan as P
+        P.CONV_COARSE_BITS = 17 if on else 15
+    elif which == "coarse11":
+        import scenesplat_amd.plan as P
+        P.CONV_COARSE_BITS = 11 if on else 13
     elif which == "mask_small":
         import scenesplat_amd.plan as P
         P.CONV_MASK_MIN_SITES = 4096 if on else 16384

@@ -452,3 +452,10 @@ def test_open_vocab_scan_against_reference_math(C):
     nv.feat_text_scan(feat.cuda(), text.cuda(), want_max=False, idx=idx.cuda(), pred_accum=pred)
     ref = torch.zeros(5000, C); ref[idx.long()] = 2 * probs
     assert torch.allclose(pred.cpu(), ref, atol=5e-4)
+
+
+@pytest.mark.parametrize("cout,taps,cin", [(32, 27, 32), (48, 125, 16), (256, 27, 72), (1, 1, 1)])
+def test_subm_weight_mirror(cout, taps, cin):
+    from scenesplat_amd import native as nv
+    w = torch.randn(cout, taps, cin, generator=torch.Generator().manual_seed(cout + cin)).to(torch.bfloat16).cuda()
+    assert torch.equal(nv.subm_weight_mirror(w), w.flip(1).permute(2, 1, 0).contiguous())
