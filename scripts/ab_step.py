@@ -36,6 +36,8 @@ def setter(on):
     elif which == "coarse11":
         import scenesplat_amd.plan as P
         P.CONV_COARSE_BITS = 11 if on else 13
+    elif which == "blaslt":
+        torch.backends.cuda.preferred_blas_library("cublaslt" if on else "cublas")
     elif which == "mask_small":
         import scenesplat_amd.plan as P
         P.CONV_MASK_MIN_SITES = 4096 if on else 16384
