@@ -32,6 +32,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n-side", type=int, default=256, help="room side; 256 -> 102,400 Gaussians")
+    ap.add_argument("--fixture", default="room", choices=["room", "uniform"],
+                    help="room = the metric's workload (SURVEY 8d); uniform = the sparse stress fixture (not the metric)")
     ap.add_argument("--attn", default="auto", choices=["auto", "simt", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -162,7 +164,11 @@ def main():
         # DDP as the reference builds it (engines/defaults.py:13-34): broadcast_buffers=False
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
                                                         gradient_as_bucket_view=True, bucket_cap_mb=100)
-    data = {k: v.to(dev) for k, v in room_chunk(n_side=args.n_side, seed=rank, lang_dim=0).items()}
+    if args.fixture == "uniform":
+        from scenesplat_amd.synthetic import uniform_chunk
+        data = {k: v.to(dev) for k, v in uniform_chunk(seed=rank).items()}
+    else:
+        data = {k: v.to(dev) for k, v in room_chunk(n_side=args.n_side, seed=rank, lang_dim=0).items()}
     n = data["feat"].shape[0]
     cot = torch.randn(n, LANG_PTV3["dec_channels"][0], device=dev, generator=torch.Generator(device=dev).manual_seed(7))
 
@@ -214,8 +220,9 @@ def main():
             "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic" if os.environ.get("SS_BENCH_REUSE_PLAN") != "1" else "synthetic, DIAGNOSTIC: plan reused (invalid as metric)",
-            "config": {"workload": "room-%d: PT-v3m1 lang-pretrain encoder (91.71M params, in=11, out=768) fwd+bwd, "
-                                   "1 chunk of %d Gaussians per GPU per step, serialization included" % (n, n),
+            "config": {"workload": (("uniform-%d (stress fixture, NOT the metric workload):" if args.fixture == "uniform" else "room-%d:")
+                                    + " PT-v3m1 lang-pretrain encoder (91.71M params, in=11, out=768) fwd+bwd, "
+                                    "1 chunk of %d Gaussians per GPU per step, serialization included") % (n, n),
                        "gaussians_per_chunk": n, "chunks_per_gpu": 1,
                        "parallelism": "dp%d" % world, "attention_kernel": "mfma" if impl == nv.ATTN_MFMA else "simt"},
         }

@@ -43,6 +43,20 @@ def room_chunk(n_side=256, seed=0, lang_dim=768, num_classes=20, batch=1):
     return out
 
 
+def uniform_chunk(n=102400, extent=(300, 300, 150), seed=0):
+    """SURVEY 8d secondary fixture "uniform-102400": n unique voxels uniform in a box (depth 9) -- the stress case:
+    ~1-2 occupied neighbours per site, irregular neighbour masks, pooled levels that barely shrink, window tails."""
+    g = torch.Generator().manual_seed(seed)
+    ex = torch.tensor(extent)
+    tot = int(ex.prod())
+    lin = torch.randperm(tot, generator=g)[:n]
+    gc = torch.stack([lin // (extent[1] * extent[2]), (lin // extent[2]) % extent[1], lin % extent[2]], 1).long()
+    coord = gc.float() * 0.02 + torch.rand(n, 3, generator=g) * 0.02
+    feat = torch.cat([torch.rand(n, 3, generator=g) * 2 - 1, torch.rand(n, 1, generator=g),
+                      torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=1), torch.rand(n, 3, generator=g) * 1.5], 1)
+    return dict(coord=coord, grid_coord=gc, feat=feat, offset=torch.tensor([n]))
+
+
 LANG_PTV3 = dict(  # configs/concat_dataset/lang-pretrain-concat-scan-ppv2-matt-mcmc-wo-normal-contrastive.py:20-54
     in_channels=11, order=("z", "z-trans", "hilbert", "hilbert-trans"), stride=(2, 2, 2),
     enc_depths=(2, 2, 2, 6), enc_channels=(32, 64, 128, 256), enc_num_head=(2, 4, 8, 16),

@@ -167,3 +167,34 @@ def test_pipeline_kernels_race_screen_and_linearity(room):
             d2, b2 = nv.linear_wgrad(xa, go, True)
             assert torch.equal(d2, dwl) and torch.equal(b2, dbl)
         assert torch.equal(dwl, go.float().t() @ xa.float()) and torch.equal(dbl, go.float().sum(0))
+
+
+def test_uniform_102400_stress_forward_backward():
+    """SURVEY 8d "uniform-102400": sparse, irregular neighbourhoods (many distinct tap masks), pooled levels
+    [102400, ~99.7k, ~81.6k, ~26.6k] with window tails at every level.  The full lang-pretrain PT-v3m1 must run
+    fwd+bwd under bf16 autocast with finite outputs / gradients, unit-scale features and every parameter touched."""
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.pointcept_api import MODELS, RUNTIME
+    from scenesplat_amd.synthetic import LANG_PTV3, uniform_chunk
+    old = dict(RUNTIME)
+    RUNTIME["attn_impl"] = nv.ATTN_MFMA; RUNTIME["conv_dtype"] = torch.bfloat16
+    try:
+        torch.manual_seed(3)
+        model = MODELS.build(dict(type="PT-v3m1", **LANG_PTV3)).cuda().train()
+        data = {k: v.cuda() for k, v in uniform_chunk().items()}
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(dict(feat=data["feat"], grid_coord=data["grid_coord"], offset=data["offset"]))
+        sizes = [lv.n for lv in out["plan"].levels]
+        assert sizes[0] == 102400 and 95000 < sizes[1] < 102400 and 70000 < sizes[2] < 95000 and 20000 < sizes[3] < 40000
+        f = out.feat.float()
+        assert f.shape == (102400, 768) and bool(torch.isfinite(f).all())
+        cot = torch.randn_like(f).to(out.feat.dtype)
+        torch.autograd.backward(out.feat, grad_tensors=cot)
+        n_par = 0
+        for name, p in model.named_parameters():
+            assert p.grad is not None, name
+            assert bool(torch.isfinite(p.grad).all()), name
+            n_par += 1
+        assert n_par > 300
+    finally:
+        RUNTIME.update(old)
