@@ -38,6 +38,11 @@ def setter(on):
         P.CONV_COARSE_BITS = 11 if on else 13
     elif which == "blaslt":
         torch.backends.cuda.preferred_blas_library("cublaslt" if on else "cublas")
+    elif which == "rowscale":
+        if on:
+            model.__dict__.pop("_draw_row_scales", None)
+        else:
+            model.__dict__["_draw_row_scales"] = lambda levels, device: None
     elif which == "mask_small":
         import scenesplat_amd.plan as P
         P.CONV_MASK_MIN_SITES = 4096 if on else 16384
