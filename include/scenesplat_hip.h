@@ -168,6 +168,12 @@ int ss_gather_add_rows(const void* a, const void* b, const int32_t* idx, void* d
                        ss_stream_t stream);
 int ss_segment_reduce(const void* src, const int32_t* indices, const int32_t* idx_ptr, void* out, int64_t n_seg,
                       int channels, int dtype, int mean, ss_stream_t stream);
+/* reduce = "min" / "max" of torch_scatter.segment_csr: out (n_seg,C) and arg (n_seg,C) int32 = source row attaining it
+ * (NULL to skip; -1 for an empty segment, whose out is 0).  Backward: dsrc (ZEROED) [arg[s][c]][c] = dout[s][c]. */
+int ss_segment_minmax(const void* src, const int32_t* indices, const int32_t* idx_ptr, void* out, int32_t* arg, int64_t n_seg,
+                      int channels, int dtype, int is_max, ss_stream_t stream);
+int ss_segment_minmax_bwd(const void* dout, const int32_t* arg, void* dsrc, int64_t n_seg, int channels, int dtype,
+                          ss_stream_t stream);
 int ss_segment_bcast(const void* dout, const int32_t* cluster, const int32_t* idx_ptr, void* dsrc, int64_t n,
                      int channels, int dtype, int mean, ss_stream_t stream);
 

@@ -39,6 +39,8 @@ PROTOTYPES = {
     "ss_subm_rulebook": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
     "ss_subm_conv_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "ss_stream_create_cu_mask": (c_i, [c_i, c_p, c_p]),
+    "ss_segment_minmax": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
+    "ss_segment_minmax_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_p]),
     "ss_subm_weight_mirror": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "ss_subm_im2col": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i64, c_p]),
     "ss_gemm8_ok": (c_i, [c_i64, c_i, c_i, c_i]),

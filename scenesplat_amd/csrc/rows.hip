@@ -145,6 +145,35 @@ __global__ void k_segment_reduce(const T* __restrict__ src, const int32_t* __res
   if (mean && e > b) acc /= (float)(e - b);
   ElemIO<T>::store(out + gid, acc);
 }
+// out[s][c] = min / max over the segment, arg[s][c] = the source ROW that attains it (first one on ties; -1 and 0 for an
+// empty segment, as torch_scatter's base value)
+template <typename T>
+__global__ void k_segment_minmax(const T* __restrict__ src, const int32_t* __restrict__ indices,
+                                 const int32_t* __restrict__ ptr, T* __restrict__ out, int32_t* __restrict__ arg,
+                                 int64_t n_seg, int C, int is_max) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_seg * C) return;
+  int64_t s = gid / C; int c = (int)(gid - s * C);
+  int b = ptr[s], e = ptr[s + 1];
+  float best = 0.f; int32_t bi = -1;
+  for (int j = b; j < e; ++j) {
+    int32_t r = indices ? indices[j] : j;
+    float v = ElemIO<T>::load(src + (int64_t)r * C + c);
+    if (bi < 0 || (is_max ? v > best : v < best) || v != v) { if (!(best != best)) { best = v; bi = r; } }
+  }
+  ElemIO<T>::store(out + gid, best);
+  if (arg) arg[gid] = bi;
+}
+// dsrc (zeroed) [arg[s][c]][c] = dout[s][c]
+template <typename T>
+__global__ void k_segment_minmax_bwd(const T* __restrict__ dout, const int32_t* __restrict__ arg, T* __restrict__ dsrc,
+                                     int64_t n_seg, int C) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_seg * C) return;
+  int c = (int)(gid % C);
+  int32_t r = arg[gid];
+  if (r >= 0) dsrc[(int64_t)r * C + c] = dout[gid];
+}
 // dsrc[i][c] = dout[cluster[i]][c] * (mean ? 1/count : 1)
 template <typename T>
 __global__ void k_segment_bcast(const T* __restrict__ dout, const int32_t* __restrict__ cluster,
@@ -179,6 +208,30 @@ extern "C" int ss_segment_reduce(const void* src, const int32_t* indices, const 
     SS_LAUNCH(k_segment_reduce<unsigned short>, g, b, 0, stream, (const unsigned short*)src, indices, idx_ptr, (unsigned short*)out, n_seg, channels, mean);
   else return SS_ERR_ARG;
   SS_CHECK_LAUNCH();
+  return SS_OK;
+}
+extern "C" int ss_segment_minmax(const void* src, const int32_t* indices, const int32_t* idx_ptr, void* out, int32_t* arg,
+                                 int64_t n_seg, int channels, int dtype, int is_max, hipStream_t stream) {
+  if (n_seg < 0 || channels <= 0) return SS_ERR_ARG;
+  if (n_seg == 0) return SS_OK;
+  dim3 g(ss_div_up(n_seg * channels, 256)), b(256);
+  if (dtype == SS_F32)
+    SS_LAUNCH(k_segment_minmax<float>, g, b, 0, stream, (const float*)src, indices, idx_ptr, (float*)out, arg, n_seg, channels, is_max);
+  else if (dtype == SS_BF16)
+    SS_LAUNCH(k_segment_minmax<unsigned short>, g, b, 0, stream, (const unsigned short*)src, indices, idx_ptr, (unsigned short*)out, arg, n_seg, channels, is_max);
+  else return SS_ERR_ARG;
+  return SS_OK;
+}
+extern "C" int ss_segment_minmax_bwd(const void* dout, const int32_t* arg, void* dsrc, int64_t n_seg, int channels, int dtype,
+                                     hipStream_t stream) {
+  if (n_seg < 0 || channels <= 0 || !arg) return SS_ERR_ARG;
+  if (n_seg == 0) return SS_OK;
+  dim3 g(ss_div_up(n_seg * channels, 256)), b(256);
+  if (dtype == SS_F32)
+    SS_LAUNCH(k_segment_minmax_bwd<float>, g, b, 0, stream, (const float*)dout, arg, (float*)dsrc, n_seg, channels);
+  else if (dtype == SS_BF16)
+    SS_LAUNCH(k_segment_minmax_bwd<unsigned short>, g, b, 0, stream, (const unsigned short*)dout, arg, (unsigned short*)dsrc, n_seg, channels);
+  else return SS_ERR_ARG;
   return SS_OK;
 }
 extern "C" int ss_segment_bcast(const void* dout, const int32_t* cluster, const int32_t* idx_ptr, void* dsrc, int64_t n,

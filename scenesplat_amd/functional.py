@@ -49,6 +49,27 @@ class _SegmentMean(torch.autograd.Function):
         return nv.segment_bcast(dout.contiguous(), lv.cluster, lv.idx_ptr, ctx.mean), None, None
 
 
+class _SegmentMinMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, level, is_max):
+        src = src.contiguous()
+        out, arg = nv.segment_minmax(src, level.indices, level.idx_ptr, level.n, is_max)
+        ctx.save_for_backward(arg)
+        ctx.n_src = src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (arg,) = ctx.saved_tensors
+        return nv.segment_minmax_bwd(dout.contiguous(), arg, ctx.n_src), None, None
+
+
+def segment_minmax(src, level, is_max):
+    """reduce="min" / "max" of torch_scatter.segment_csr over each cluster of `level`; the gradient goes to the row that
+    attained the extremum (first one on ties)."""
+    return _SegmentMinMax.apply(src, level, is_max)
+
+
 def segment_mean(src, level, mean=True):
     """Pool rows of the finer level into `level` (the coarser one): mean (or sum) over each cluster."""
     return _SegmentMean.apply(src, level, mean)

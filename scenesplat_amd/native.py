@@ -469,6 +469,29 @@ def segment_reduce(src, indices, idx_ptr, n_seg, mean):
     return out
 
 
+def segment_minmax(src, indices, idx_ptr, n_seg, is_max):
+    """-> (out (n_seg,C), arg (n_seg,C) int32 source rows)"""
+    _req(src, None, "src"); _req(idx_ptr, torch.int32, "idx_ptr")
+    if indices is not None:
+        _req(indices, torch.int32, "indices")
+    if idx_ptr.numel() < n_seg + 1:
+        raise RuntimeError("idx_ptr shorter than n_seg+1")
+    C = src.shape[1]
+    out = torch.empty((n_seg, C), dtype=src.dtype, device=src.device)
+    arg = torch.empty((n_seg, C), dtype=torch.int32, device=src.device)
+    check(lib().ss_segment_minmax(_p(src), _p(indices), _p(idx_ptr), _p(out), _p(arg), n_seg, C, dtype_code(src), int(is_max),
+                                  _stream()), "ss_segment_minmax")
+    return out, arg
+
+
+def segment_minmax_bwd(dout, arg, n_src):
+    _req(dout, None, "dout"); _req(arg, torch.int32, "arg", tuple(dout.shape))
+    n_seg, C = dout.shape
+    dsrc = torch.zeros((n_src, C), dtype=dout.dtype, device=dout.device)
+    check(lib().ss_segment_minmax_bwd(_p(dout), _p(arg), _p(dsrc), n_seg, C, dtype_code(dout), _stream()), "ss_segment_minmax_bwd")
+    return dsrc
+
+
 def segment_bcast(dout, cluster, idx_ptr, mean):
     _req(dout, None, "dout"); _req(cluster, torch.int32, "cluster"); _req(idx_ptr, torch.int32, "idx_ptr")
     n, C = cluster.numel(), dout.shape[1]

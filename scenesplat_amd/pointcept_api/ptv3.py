@@ -194,8 +194,8 @@ class SerializedPooling(PointModule):
     def __init__(self, in_channels, out_channels, stride=2, norm_layer=None, act_layer=None, reduce="mean",
                  shuffle_orders=True, traceable=True):
         super().__init__()
-        if reduce not in ("mean", "sum"):
-            raise NotImplementedError("grid pool reduce 'min'/'max' is not on the HIP path (every reference config uses 'mean')")
+        if reduce not in ("mean", "sum", "min", "max"):
+            raise ValueError(f"unknown reduce {reduce!r} (torch_scatter.segment_csr: sum / mean / min / max)")
         self.reduce = reduce
         self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
         self.shuffle_orders = shuffle_orders
@@ -204,7 +204,10 @@ class SerializedPooling(PointModule):
         self.act = act_layer() if act_layer is not None else None
 
     def forward(self, x, coarse_level):
-        x = SF.segment_mean(_lin(self.proj, x), coarse_level, mean=(self.reduce == "mean"))
+        if self.reduce in ("min", "max"):
+            x = SF.segment_minmax(_lin(self.proj, x), coarse_level, self.reduce == "max")
+        else:
+            x = SF.segment_mean(_lin(self.proj, x), coarse_level, mean=(self.reduce == "mean"))
         return _norm_act(x, self.norm[0] if self.norm is not None else None, self.act)
 
 

@@ -459,3 +459,35 @@ def test_subm_weight_mirror(cout, taps, cin):
     from scenesplat_amd import native as nv
     w = torch.randn(cout, taps, cin, generator=torch.Generator().manual_seed(cout + cin)).to(torch.bfloat16).cuda()
     assert torch.equal(nv.subm_weight_mirror(w), w.flip(1).permute(2, 1, 0).contiguous())
+
+
+@pytest.mark.parametrize("reduce", ["min", "max"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_segment_minmax_against_oracle(reduce, dtype):
+    """reduce='min'/'max' of torch_scatter.segment_csr (row a14) on a pooled level: values and the gradient routing
+    to the arg rows, against the oracle's scatter_reduce restatement (distinct values -> no ties)."""
+    from scenesplat_amd import functional as SF
+    from scenesplat_amd.plan import build_plan
+    g = torch.Generator().manual_seed(11)
+    gc = torch.unique(torch.randint(0, 24, (3000, 3), generator=g), dim=0)
+    n = len(gc)
+    plan = build_plan(gc.cuda(), torch.tensor([n // 2, n]).cuda(), ORD, (2,))
+    fine, coarse = plan.levels
+    C = 20
+    # all distinct and never exactly 0: torch's scatter_reduce backward counts the zero-initialised `self` as a tie
+    # even with include_self=False (an artefact of the oracle's restatement, not of segment_csr)
+    x = -(torch.randperm(n * C, generator=g).float().reshape(n, C) + 1) / (n * C)
+    if dtype == torch.bfloat16:      # bf16-exact values that stay distinct inside every cluster (<= 8 rows)
+        idx0 = coarse.indices.long().cpu(); ptr0 = coarse.idx_ptr.cpu()[: coarse.n + 1].long()
+        seg = torch.repeat_interleave(torch.arange(coarse.n), ptr0[1:] - ptr0[:-1])
+        pos = torch.empty(n, dtype=torch.long); pos[idx0] = torch.arange(n) - ptr0[seg]
+        x = -(((pos.unsqueeze(1) * 7 + torch.arange(C).unsqueeze(0) * 3) % 11) + 1).float() / 8.0
+    xg = x.to(dtype).cuda().requires_grad_(True)
+    y = SF.segment_minmax(xg, coarse, reduce == "max")
+    idx = coarse.indices.long().cpu(); ptr = coarse.idx_ptr.cpu()[: coarse.n + 1]
+    xo = x.clone().requires_grad_(True)
+    yo = oops.segment_csr(xo[idx], ptr, reduce)
+    assert torch.equal(y.float().cpu(), yo.detach().to(dtype).float())
+    cot = torch.randn(coarse.n, C, generator=g).to(dtype)
+    y.backward(cot.cuda()); yo.backward(cot.float())
+    assert torch.equal(xg.grad.float().cpu(), xo.grad.to(dtype).float())
