@@ -357,6 +357,48 @@ class AttentionStep2WithRelPosValue(Function):
 attention_step2_with_rel_pos_value = AttentionStep2WithRelPosValue.apply
 
 
+# ---- pointops2 v2 / v3 call forms (libs/pointops2/functions/pointops.py:166-957) ------------------------------------
+# The reference's _v2 / _v3 kernels compute the SAME quantities as the v1 ones; they only take the query side as CSR
+# offsets (pairs sorted by query, `index0_offsets` (N+1), `n_max` = longest row -- a launch-geometry hint of the CUDA
+# kernels) and fuse the q- and k-table dot products.  Here they are call-compatible fronts of the same HIP kernels.
+def _index_from_offsets(offsets, m):
+    offsets = offsets.to(torch.int64)
+    counts = offsets[1:] - offsets[:-1]
+    idx = torch.repeat_interleave(torch.arange(counts.numel(), device=offsets.device), counts, output_size=int(m))
+    return idx.to(torch.int32)
+
+
+def attention_step1_v2(q, k, index1, index0_offsets, n_max=None):
+    """attn (M, h) = q[index0[m]] . k[index1[m]] with index0 given as CSR offsets (pointops.py:166-254)."""
+    return attention_step1(q, k, _index_from_offsets(index0_offsets, index1.shape[0]), index1)
+
+
+def attention_step2_v2(attn, v, index0, index1):
+    """Same contract as attention_step2 (pointops.py:334-400 launches the v1 kernel)."""
+    return attention_step2(attn, v, index0, index1)
+
+
+def dot_prod_with_idx_v2(q, index_q, k, index_k, table_q, table_k, rel_idx):
+    """out (M, h) = q[index_q] . table_q[rel_idx] + k[index_k] . table_k[rel_idx] (pointops.py:472-625)."""
+    return dot_prod_with_idx(q, index_q, table_q, rel_idx) + dot_prod_with_idx(k, index_k, table_k, rel_idx)
+
+
+def dot_prod_with_idx_v3(q, index_q_offsets, n_max, k, index_k, table_q, table_k, rel_idx):
+    """dot_prod_with_idx_v2 with the query index as CSR offsets (pointops.py:628-751)."""
+    index_q = _index_from_offsets(index_q_offsets, index_k.shape[0])
+    return dot_prod_with_idx_v2(q, index_q, k, index_k, table_q, table_k, rel_idx)
+
+
+def attention_step2_with_rel_pos_value_v2(attn, v, index0_offsets, n_max, index1, table, rel_idx):
+    """attention_step2_with_rel_pos_value with index0 as CSR offsets (pointops.py:850-957)."""
+    index0 = _index_from_offsets(index0_offsets, index1.shape[0])
+    return attention_step2_with_rel_pos_value(attn, v, index0, index1, table, rel_idx)
+
+
+# pointops2 spellings of the shared ops (pointops.py:30,52,86,1054,1107,1190)
+furthestsampling = farthest_point_sampling
+
+
 # ---- pointgroup_ops (functions/functions.py) ----------------------------------------------------------
 def ballquery_batch_p(coords, batch_idxs, batch_offsets, radius, meanActive):
     """-> idx (nActive) int32, start_len (n, 2) int32.  Two-pass and deterministic; the buffer is sized

@@ -211,3 +211,41 @@ def test_gpu_grid_sample_train_semantics():
     assert np.array_equal(gc_all[sel][inv], gc_all)                         # inverse maps each point to its voxel's row
     res2 = grid_sample_train(coord.cuda(), gs)
     assert not np.array_equal(sel, res2["idx_unique"].cpu().numpy())         # random representative
+
+
+def test_pointops2_v2_v3_call_forms():
+    """pointops2's _v2 / _v3 call forms (CSR query offsets, fused q/k table dot products) against the plain-torch
+    statement of the same quantities (libs/pointops2/functions/pointops.py:166-957)."""
+    from scenesplat_amd import pointops as po
+    g = np.random.default_rng(12)
+    n, h, c, L = 60, 2, 8, 5
+    counts = g.integers(0, 9, n)                       # pairs per query, sorted by query (some queries have none)
+    m = int(counts.sum())
+    i0 = np.repeat(np.arange(n), counts)
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    i1 = g.integers(0, n, m)
+    q, k, v = (g.standard_normal((n, h, c)).astype(np.float32) for _ in range(3))
+    tq_, tk_ = (g.standard_normal((L, h, c, 3)).astype(np.float32) for _ in range(2))
+    rel = g.integers(0, L, (m, 3))
+    attn = g.standard_normal((m, h)).astype(np.float32)
+    n_max = int(counts.max())
+    o1 = po.attention_step1_v2(cu(q), cu(k), cu(i1, torch.int32), cu(offs, torch.int32), n_max)
+    assert np.allclose(o1.cpu().numpy(), opo.attention_relation(q, k, None, i0, i1), atol=1e-4)
+    o2 = po.attention_step2_v2(cu(attn), cu(v), cu(i0, torch.int32), cu(i1, torch.int32))
+    assert np.allclose(o2.cpu().numpy(), opo.attention_fusion(attn, v, i0, i1, n), atol=1e-4)
+    ref = opo.rpe_dot_prod(q, i0, tq_, rel) + opo.rpe_dot_prod(k, i1, tk_, rel)
+    tq, tk, ttq, ttk = (cu(x).requires_grad_(True) for x in (q, k, tq_, tk_))
+    o3 = po.dot_prod_with_idx_v2(tq, cu(i0, torch.int32), tk, cu(i1, torch.int32), ttq, ttk, cu(rel, torch.int32))
+    assert np.allclose(o3.detach().cpu().numpy(), ref, atol=1e-4)
+    o4 = po.dot_prod_with_idx_v3(cu(q), cu(offs, torch.int32), n_max, cu(k), cu(i1, torch.int32), cu(tq_), cu(tk_), cu(rel, torch.int32))
+    assert np.allclose(o4.cpu().numpy(), ref, atol=1e-4)
+    cot = g.standard_normal((m, h)).astype(np.float32)
+    (o3 * cu(cot)).sum().backward()
+    rq, rk, rtq, rtk = (torch.tensor(x, requires_grad=True) for x in (q, k, tq_, tk_))
+    r = sum((rq[i0] * rtq[rel[:, d], :, :, d]).sum(-1) + (rk[i1] * rtk[rel[:, d], :, :, d]).sum(-1) for d in range(3))
+    (r * torch.tensor(cot)).sum().backward()
+    for a_, b_ in ((tq, rq), (tk, rk), (ttq, rtq), (ttk, rtk)):
+        assert torch.allclose(a_.grad.cpu(), b_.grad, atol=3e-4)
+    o5 = po.attention_step2_with_rel_pos_value_v2(cu(attn), cu(v), cu(offs, torch.int32), n_max, cu(i1, torch.int32), cu(tq_),
+                                                  cu(rel, torch.int32))
+    assert np.allclose(o5.cpu().numpy(), opo.rpe_attn_step2(attn, v, i0, i1, tq_, rel, n), atol=1e-4)
