@@ -135,6 +135,15 @@ int ss_subm_conv_wgrad(const void* in, const void* dout, const int32_t* nbr, con
 int ss_add_layernorm_fwd(const void* x, int x_dtype, const void* y, int y_dtype, const float* rowscale,
                          const float* gamma, const float* beta, float eps, void* xout, int xout_dtype, void* xcopy_bf16,
                          void* h, int h_dtype, float* mean, float* rstd, int64_t n, int channels, ss_stream_t stream);
+/* First seam of a pre-norm Block in one pass (ptv3:318-325): xout = x + LN0(t), h = LN1(xout).  stats (n,4) f32 = mean0, rstd0,
+ * mean1, rstd1.  Backward: g_x = g_xout + LN1'(g_h), g_t = LN0'(g_x); part (4, nblocks, C) f32 = per-block partial sums of
+ * dgamma0, dbeta0, dgamma1, dbeta1 (nblocks = ss_add_layernorm_bwd_blocks(n)); either of g_xout / g_h may be NULL. */
+int ss_ln_add_ln_fwd(const void* x, int x_dtype, const void* t, int t_dtype, const float* gamma0, const float* beta0, float eps0,
+                     const float* gamma1, const float* beta1, float eps1, float* xout, void* h, int h_dtype, float* stats,
+                     int64_t n, int channels, ss_stream_t stream);
+int ss_ln_add_ln_bwd(const float* g_xout, const void* g_h, int g_h_dtype, const float* xout, const void* t, int t_dtype,
+                     const float* stats, const float* gamma0, const float* gamma1, void* g_x, int g_x_dtype, void* g_t,
+                     int g_t_dtype, float* part, int64_t n, int channels, int nblocks, ss_stream_t stream);
 int ss_add_layernorm_bwd_blocks(int64_t n);
 /* g_v = g_xout + g_xcopy + LN'(g_h); g_x = g_v; g_y = rowscale*g_v; dgamma/dbeta partials (nblocks, C) */
 int ss_add_layernorm_bwd(const void* g_xout, int g_xout_dtype, const void* g_xcopy, int g_xcopy_dtype, const void* g_h,

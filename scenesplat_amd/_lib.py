@@ -39,6 +39,8 @@ PROTOTYPES = {
     "ss_subm_rulebook": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_i, c_i, c_p, c_p]),
     "ss_subm_conv_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "ss_stream_create_cu_mask": (c_i, [c_i, c_p, c_p]),
+    "ss_ln_add_ln_fwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_f, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_i64, c_i, c_p]),
+    "ss_ln_add_ln_bwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i64, c_i, c_i, c_p]),
     "ss_segment_minmax": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "ss_segment_minmax_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_p]),
     "ss_subm_weight_mirror": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -38,14 +38,16 @@ extern "C" int ss_window_attn_bwd(const void* qkv, const void* out, const void* 
   if (num_windows == 0) return SS_OK;
   float* delta = (float*)workspace;
   void* extra = (char*)workspace + al256((size_t)n_pad * num_heads * 4);
-  int rc = ss_attn_delta(out, dout, sidx, delta, n_pad, channels, num_heads, dtype, stream);
-  if (rc) return rc;
+  int rc = SS_OK;
   if (impl == SS_ATTN_MFMA && max_window > SS_ATTN_MFMA_MAX_WINDOW) impl = SS_ATTN_SIMT;
+  if (!(impl == SS_ATTN_MFMA && dtype == SS_BF16))      // the MFMA dQ kernel computes delta itself
+    rc = ss_attn_delta(out, dout, sidx, delta, n_pad, channels, num_heads, dtype, stream);
+  if (rc) return rc;
   if (impl == SS_ATTN_SIMT)
     rc = ss_attn_bwd_simt(qkv, dout, lse, delta, gidx, sidx, win_start, num_windows, dqkv, extra, channels, num_heads,
                           scale, dtype, stream);
   else if (impl == SS_ATTN_MFMA && dtype == SS_BF16)
-    rc = ss_attn_bwd_mfma(qkv, dout, lse, delta, gidx, sidx, win_start, num_windows, max_window, dqkv, extra, channels,
+    rc = ss_attn_bwd_mfma(qkv, dout, out, lse, delta, gidx, sidx, win_start, num_windows, max_window, dqkv, extra, channels,
                           num_heads, scale, stream);
   else
     return SS_ERR_ARG;

@@ -12,6 +12,7 @@ int ss_attn_bwd_simt(const void* qkv, const void* dout, const float* lse, const 
                      float scale, int dtype, hipStream_t st);
 int ss_attn_fwd_mfma(const void* qkv, const int32_t* gidx, const int32_t* sidx, const int32_t* win_start, int W,
                      int max_window, void* out, float* lse, int C, int H, float scale, hipStream_t st);
-int ss_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const float* delta, const int32_t* gidx,
+// delta (n_pad, H) is an OUTPUT of the dQ kernel here (rowsum(out o dout), consumed by the dK/dV kernel): no ss_attn_delta pass
+int ss_attn_bwd_mfma(const void* qkv, const void* dout, const void* out, const float* lse, float* delta, const int32_t* gidx,
                      const int32_t* sidx, const int32_t* win_start, int W, int max_window, void* dqkv, void* extra,
                      int C, int H, float scale, hipStream_t st);

@@ -310,7 +310,8 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
 template <int D>
 __global__ void __launch_bounds__(FA_THREADS, FA_BWD_MIN_BLOCKS)
 k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ dout,
-                   const float* __restrict__ lse, const float* __restrict__ delta, const int32_t* __restrict__ gidx,
+                   const unsigned short* __restrict__ outp, const float* __restrict__ lse, float* __restrict__ delta,
+                   const int32_t* __restrict__ gidx,
                    const int32_t* __restrict__ sidx, const int32_t* __restrict__ win_start,
                    unsigned short* __restrict__ dqkv, int C, int H, float scale, int qchunks) {
   using A = ACfg<D>;
@@ -346,15 +347,26 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
     int64_t row = ok ? gidx[p0 + slot] : -1;
     srow[qt] = ok ? sidx[p0 + slot] : -1;
     lse2[qt] = ok ? lse[(int64_t)(p0 + slot) * H + h] * 1.44269504088896340736f : 0.f;
-    dl[qt] = ok ? delta[(int64_t)(p0 + slot) * H + h] : 0.f;
+    // delta = rowsum(O o dO) of this query is computed HERE (the dO fragment is loaded anyway) and published for the
+    // dK/dV kernel, which runs after this one: no separate delta pass over O and dO
+    float dsum = 0.f;
 #pragma unroll
     for (int ks = 0; ks < A::NKS; ++ks) {
       int d0 = 32 * ks + 8 * g;
-      uint4 v = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0);
+      uint4 v = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0), o = make_uint4(0, 0, 0, 0);
       if (row >= 0 && d0 < D) v = ld16(qkv + row * C3 + h * D + d0);
-      if (srow[qt] >= 0 && d0 < D) u = ld16(dout + (int64_t)srow[qt] * C + h * D + d0);
+      if (srow[qt] >= 0 && d0 < D) { u = ld16(dout + (int64_t)srow[qt] * C + h * D + d0); o = ld16(outp + (int64_t)srow[qt] * C + h * D + d0); }
       qf[qt][ks] = as_bf8(v); gf[qt][ks] = as_bf8(u);
+      const unsigned int* uu = reinterpret_cast<const unsigned int*>(&u);
+      const unsigned int* uo = reinterpret_cast<const unsigned int*>(&o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dsum += __uint_as_float(uu[j] << 16) * __uint_as_float(uo[j] << 16);
+        dsum += __uint_as_float(uu[j] & 0xffff0000u) * __uint_as_float(uo[j] & 0xffff0000u);
+      }
     }
+    dl[qt] = xsum4(dsum);
+    if (ok && g == 0) delta[(int64_t)(p0 + slot) * H + h] = dl[qt];
   }
   f32x4_t dq[A::NDT][FA_NT];
 #pragma unroll
@@ -679,7 +691,7 @@ int ss_attn_fwd_mfma(const void* qkv, const int32_t* gidx, const int32_t* sidx, 
   return SS_OK;
 }
 
-int ss_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const float* delta, const int32_t* gidx,
+int ss_attn_bwd_mfma(const void* qkv, const void* dout, const void* out, const float* lse, float* delta, const int32_t* gidx,
                      const int32_t* sidx, const int32_t* win_start, int W, int max_window, void* dqkv, void* extra,
                      int C, int H, float scale, hipStream_t st) {
   const int D = C / H;
@@ -690,8 +702,8 @@ int ss_attn_bwd_mfma(const void* qkv, const void* dout, const float* lse, const 
   unsigned short* dq = (unsigned short*)dqkv; unsigned short* ex = (unsigned short*)extra;
 #define SS_MB_CASE(DD)                                                                                              \
   case DD:                                                                                                          \
-    SS_LAUNCH((k_attn_bwd_dq_mfma<DD>), g, b, 0, st, q, go, lse, delta, gidx, sidx, win_start, dq, C, H, scale, chunks); \
-    SS_LAUNCH((k_attn_bwd_dkv_mfma<DD>), g, b, 0, st, q, go, lse, delta, gidx, sidx, win_start, dq, ex, C, H, scale, chunks); \
+    SS_LAUNCH((k_attn_bwd_dq_mfma<DD>), g, b, 0, st, q, go, (const unsigned short*)out, lse, delta, gidx, sidx, win_start, dq, C, H, scale, chunks); \
+    SS_LAUNCH((k_attn_bwd_dkv_mfma<DD>), g, b, 0, st, q, go, lse, (const float*)delta, gidx, sidx, win_start, dq, ex, C, H, scale, chunks); \
     break;
   switch (D) {
     SS_MB_CASE(16) SS_MB_CASE(32) SS_MB_CASE(48) SS_MB_CASE(64)

@@ -202,6 +202,200 @@ extern "C" int ss_add_layernorm_bwd(const void* g_xout, int g_xout_dtype, const 
 }
 
 // =====================================================================================
+// First seam of a pre-norm Block (ptv3:318-325): x += LN0(t); h = LN1(x) in ONE pass:
+//     u = LN0(t) * gamma0 + beta0 (kept in fp32 registers, never written);  v = x + u;  xout = v;  h = LN1(v)*gamma1 + beta1
+// backward: g_v = g_xout + LN1'(g_h);  g_x = g_v;  g_t = LN0'(g_v);  per-block partials of the four affine gradients.
+// Saves the LN0 output round trip (2 x n x C bf16 forward, 2 x backward) and one launch each way per Block.
+// =====================================================================================
+template <int IT>
+__global__ void __launch_bounds__(LN_THREADS)
+k_ln_add_ln_fwd(const void* __restrict__ x, int x_dt, const void* __restrict__ t, int t_dt, const float* __restrict__ gamma0,
+                const float* __restrict__ beta0, float eps0, const float* __restrict__ gamma1, const float* __restrict__ beta1,
+                float eps1, float* __restrict__ xout, void* __restrict__ h, int h_dt, float* __restrict__ stats, int64_t n,
+                int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (LN_THREADS / 64) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  float4 v[IT];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int j = i * 256 + lane * 4;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < C) { v[i] = ln_ld4(t, t_dt, row * C + j); sum += v[i].x + v[i].y + v[i].z + v[i].w; }
+  }
+  const float mu0 = wave_reduce_sum(sum) / C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int j = i * 256 + lane * 4;
+    if (j < C) { float a = v[i].x - mu0, b = v[i].y - mu0, c = v[i].z - mu0, d = v[i].w - mu0; sq += a * a + b * b + c * c + d * d; }
+  }
+  const float r0 = rsqrtf(wave_reduce_sum(sq) / C + eps0);
+  sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int j = i * 256 + lane * 4;
+    if (j < C) {
+      float4 g = *reinterpret_cast<const float4*>(gamma0 + j), b = *reinterpret_cast<const float4*>(beta0 + j);
+      float4 a = ln_ld4(x, x_dt, row * C + j);
+      a.x += (v[i].x - mu0) * r0 * g.x + b.x; a.y += (v[i].y - mu0) * r0 * g.y + b.y;
+      a.z += (v[i].z - mu0) * r0 * g.z + b.z; a.w += (v[i].w - mu0) * r0 * g.w + b.w;
+      v[i] = a;
+      *reinterpret_cast<float4*>(xout + row * C + j) = a;
+      sum += a.x + a.y + a.z + a.w;
+    }
+  }
+  const float mu1 = wave_reduce_sum(sum) / C;
+  sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int j = i * 256 + lane * 4;
+    if (j < C) { float a = v[i].x - mu1, b = v[i].y - mu1, c = v[i].z - mu1, d = v[i].w - mu1; sq += a * a + b * b + c * c + d * d; }
+  }
+  const float r1 = rsqrtf(wave_reduce_sum(sq) / C + eps1);
+  if (lane == 0) *reinterpret_cast<float4*>(stats + row * 4) = make_float4(mu0, r0, mu1, r1);
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int j = i * 256 + lane * 4;
+    if (j < C) {
+      float4 g = *reinterpret_cast<const float4*>(gamma1 + j), b = *reinterpret_cast<const float4*>(beta1 + j);
+      ln_st4(h, h_dt, row * C + j, make_float4((v[i].x - mu1) * r1 * g.x + b.x, (v[i].y - mu1) * r1 * g.y + b.y,
+                                               (v[i].z - mu1) * r1 * g.z + b.z, (v[i].w - mu1) * r1 * g.w + b.w));
+    }
+  }
+}
+
+// LayerNorm input gradient of one row held as xh (normalised input) and gy (= g_out * gamma): r * (gy - mean(gy) - xh * mean(gy*xh))
+#define LN_ROW_BWD(XH, GY, R, OUT)                                                                        \
+  {                                                                                                       \
+    float c1_ = 0.f, c2_ = 0.f;                                                                           \
+    _Pragma("unroll") for (int i = 0; i < IT; ++i) {                                                      \
+      c1_ += GY[i].x + GY[i].y + GY[i].z + GY[i].w;                                                       \
+      c2_ += GY[i].x * XH[i].x + GY[i].y * XH[i].y + GY[i].z * XH[i].z + GY[i].w * XH[i].w;               \
+    }                                                                                                     \
+    c1_ = wave_reduce_sum(c1_) / C; c2_ = wave_reduce_sum(c2_) / C;                                       \
+    _Pragma("unroll") for (int i = 0; i < IT; ++i)                                                        \
+      OUT[i] = make_float4(R * (GY[i].x - c1_ - XH[i].x * c2_), R * (GY[i].y - c1_ - XH[i].y * c2_),      \
+                           R * (GY[i].z - c1_ - XH[i].z * c2_), R * (GY[i].w - c1_ - XH[i].w * c2_));     \
+  }
+
+template <int IT>
+__global__ void __launch_bounds__(LN_THREADS)
+k_ln_add_ln_bwd(const float* __restrict__ g_xout, const void* __restrict__ g_h, int gh_dt, const float* __restrict__ xout,
+                const void* __restrict__ t, int t_dt, const float* __restrict__ stats, const float* __restrict__ gamma0,
+                const float* __restrict__ gamma1, void* __restrict__ g_x, int gx_dt, void* __restrict__ g_t, int gt_dt,
+                float* __restrict__ part /* [4][nblocks][C]: dgamma0 dbeta0 dgamma1 dbeta1 */, int64_t n, int C) {
+  __shared__ float red[4][LN_THREADS / 64][IT * 4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int waves_total = gridDim.x * (LN_THREADS / 64);
+  float4 dg0[IT], db0[IT], dg1[IT], db1[IT], gm0[IT], gm1[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    dg0[i] = make_float4(0.f, 0.f, 0.f, 0.f); db0[i] = dg0[i]; dg1[i] = dg0[i]; db1[i] = dg0[i]; gm0[i] = dg0[i]; gm1[i] = dg0[i];
+    int j = i * 256 + lane * 4;
+    if (j < C) { gm0[i] = *reinterpret_cast<const float4*>(gamma0 + j); gm1[i] = *reinterpret_cast<const float4*>(gamma1 + j); }
+  }
+  for (int64_t row = (int64_t)blockIdx.x * (LN_THREADS / 64) + wave; row < n; row += waves_total) {
+    const float4 st = *reinterpret_cast<const float4*>(stats + row * 4);
+    float4 xh[IT], gy[IT], gv[IT];
+    // ---- LN1 backward on v = xout
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int j = i * 256 + lane * 4;
+      xh[i] = make_float4(0.f, 0.f, 0.f, 0.f); gy[i] = xh[i];
+      if (j < C) {
+        float4 a = *reinterpret_cast<const float4*>(xout + row * C + j), g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g_h) g = ln_ld4(g_h, gh_dt, row * C + j);
+        xh[i] = make_float4((a.x - st.z) * st.w, (a.y - st.z) * st.w, (a.z - st.z) * st.w, (a.w - st.z) * st.w);
+        gy[i] = make_float4(g.x * gm1[i].x, g.y * gm1[i].y, g.z * gm1[i].z, g.w * gm1[i].w);
+        dg1[i].x += g.x * xh[i].x; dg1[i].y += g.y * xh[i].y; dg1[i].z += g.z * xh[i].z; dg1[i].w += g.w * xh[i].w;
+        db1[i].x += g.x; db1[i].y += g.y; db1[i].z += g.z; db1[i].w += g.w;
+      }
+    }
+    LN_ROW_BWD(xh, gy, st.w, gv)
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int j = i * 256 + lane * 4;
+      if (j < C) {
+        if (g_xout) { float4 e = *reinterpret_cast<const float4*>(g_xout + row * C + j); gv[i].x += e.x; gv[i].y += e.y; gv[i].z += e.z; gv[i].w += e.w; }
+        ln_st4(g_x, gx_dt, row * C + j, gv[i]);
+      } else {
+        gv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    // ---- LN0 backward on t with upstream gradient g_v
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int j = i * 256 + lane * 4;
+      xh[i] = make_float4(0.f, 0.f, 0.f, 0.f); gy[i] = xh[i];
+      if (j < C) {
+        float4 a = ln_ld4(t, t_dt, row * C + j);
+        xh[i] = make_float4((a.x - st.x) * st.y, (a.y - st.x) * st.y, (a.z - st.x) * st.y, (a.w - st.x) * st.y);
+        gy[i] = make_float4(gv[i].x * gm0[i].x, gv[i].y * gm0[i].y, gv[i].z * gm0[i].z, gv[i].w * gm0[i].w);
+        dg0[i].x += gv[i].x * xh[i].x; dg0[i].y += gv[i].y * xh[i].y; dg0[i].z += gv[i].z * xh[i].z; dg0[i].w += gv[i].w * xh[i].w;
+        db0[i].x += gv[i].x; db0[i].y += gv[i].y; db0[i].z += gv[i].z; db0[i].w += gv[i].w;
+      }
+    }
+    LN_ROW_BWD(xh, gy, st.y, gv)
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int j = i * 256 + lane * 4;
+      if (j < C) ln_st4(g_t, gt_dt, row * C + j, gv[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    red[0][wave][i * 4 + 0][lane] = dg0[i].x; red[0][wave][i * 4 + 1][lane] = dg0[i].y; red[0][wave][i * 4 + 2][lane] = dg0[i].z; red[0][wave][i * 4 + 3][lane] = dg0[i].w;
+    red[1][wave][i * 4 + 0][lane] = db0[i].x; red[1][wave][i * 4 + 1][lane] = db0[i].y; red[1][wave][i * 4 + 2][lane] = db0[i].z; red[1][wave][i * 4 + 3][lane] = db0[i].w;
+    red[2][wave][i * 4 + 0][lane] = dg1[i].x; red[2][wave][i * 4 + 1][lane] = dg1[i].y; red[2][wave][i * 4 + 2][lane] = dg1[i].z; red[2][wave][i * 4 + 3][lane] = dg1[i].w;
+    red[3][wave][i * 4 + 0][lane] = db1[i].x; red[3][wave][i * 4 + 1][lane] = db1[i].y; red[3][wave][i * 4 + 2][lane] = db1[i].z; red[3][wave][i * 4 + 3][lane] = db1[i].w;
+  }
+  __syncthreads();
+  {
+    const int q = wave;                            // wave q reduces partial array q
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int j = i * 256 + lane * 4 + e;
+        if (j < C) {
+          float a = 0.f;
+          for (int w = 0; w < LN_THREADS / 64; ++w) a += red[q][w][i * 4 + e][lane];
+          part[((int64_t)q * gridDim.x + blockIdx.x) * C + j] = a;
+        }
+      }
+  }
+}
+#undef LN_ROW_BWD
+
+extern "C" int ss_ln_add_ln_fwd(const void* x, int x_dtype, const void* t, int t_dtype, const float* gamma0, const float* beta0,
+                                float eps0, const float* gamma1, const float* beta1, float eps1, float* xout, void* h,
+                                int h_dtype, float* stats, int64_t n, int channels, hipStream_t stream) {
+  if (n < 0 || channels <= 0 || (channels & 3) || channels > LN_MAXIT * 256) return SS_ERR_ARG;
+  if (!x || !t || !gamma0 || !beta0 || !gamma1 || !beta1 || !xout || !h || !stats) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  dim3 g(ss_div_up(n, LN_THREADS / 64)), b(LN_THREADS);
+#define SS_LN2_FWD(ITN) SS_LAUNCH(k_ln_add_ln_fwd<ITN>, g, b, 0, stream, x, x_dtype, t, t_dtype, gamma0, beta0, eps0, gamma1, beta1, eps1, xout, h, h_dtype, stats, n, channels)
+  switch ((channels + 255) / 256) { case 1: SS_LN2_FWD(1); break; case 2: SS_LN2_FWD(2); break; case 3: SS_LN2_FWD(3); break; default: SS_LN2_FWD(4); break; }
+#undef SS_LN2_FWD
+  return SS_OK;
+}
+
+extern "C" int ss_ln_add_ln_bwd(const float* g_xout, const void* g_h, int g_h_dtype, const float* xout, const void* t, int t_dtype,
+                                const float* stats, const float* gamma0, const float* gamma1, void* g_x, int g_x_dtype, void* g_t,
+                                int g_t_dtype, float* part, int64_t n, int channels, int nblocks, hipStream_t stream) {
+  if (n < 0 || channels <= 0 || (channels & 3) || channels > LN_MAXIT * 256 || nblocks < 1) return SS_ERR_ARG;
+  if (!xout || !t || !stats || !gamma0 || !gamma1 || !g_x || !g_t || !part || (!g_xout && !g_h)) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  dim3 g(nblocks), b(LN_THREADS);
+#define SS_LN2_BWD(ITN) SS_LAUNCH(k_ln_add_ln_bwd<ITN>, g, b, 0, stream, g_xout, g_h, g_h_dtype, xout, t, t_dtype, stats, gamma0, gamma1, g_x, g_x_dtype, g_t, g_t_dtype, part, n, channels)
+  switch ((channels + 255) / 256) { case 1: SS_LN2_BWD(1); break; case 2: SS_LN2_BWD(2); break; case 3: SS_LN2_BWD(3); break; default: SS_LN2_BWD(4); break; }
+#undef SS_LN2_BWD
+  return SS_OK;
+}
+
+// =====================================================================================
 // Fused BatchNorm1d (+ exact erf GELU) over (n, C) rows: pooling / unpooling / stem norms
 // (ptv3:581 eps 1e-3; ptv3:439-442, 461-467, 508-511).  Column statistics use the same
 // wave-per-row, lane-per-4-columns mapping as the LayerNorm backward: per-lane register partials

@@ -402,7 +402,7 @@ class _Linear(torch.autograd.Function):
                 else:
                     dw = nv.linear_wgrad(x, dy).to(w_dtype)
             else:
-                dw = (dy.t() @ x).to(w_dtype)
+                dw = _mm_f32(dy.t(), x).to(w_dtype)     # small levels: library GEMM, fp32 out where aten::mm.dtype exists
         if want_db:
             db = dy.sum(0, dtype=torch.float32).to(w_dtype)
         return dx, dw, db
@@ -468,6 +468,36 @@ class _AddLayerNorm(torch.autograd.Function):
         g_x, g_y, dg, db = nv.add_layernorm_bwd(g_xout, g_xcopy, g_h, xout, mean, rstd, g32, rowscale, x_dt, y_dt)
         return (g_x, g_y, None, dg.to(g_dt) if dg is not None else None, db.to(g_dt) if db is not None else None,
                 None, None, None)
+
+
+class _LnAddLn(torch.autograd.Function):
+    """First seam of a pre-norm Block: (x, t) -> xout = x + LN0(t) [fp32], h = LN1(xout); one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, x, t, g0, b0, eps0, g1, b1, eps1, h_dtype):
+        x, t = x.contiguous(), t.contiguous()
+        p32 = [p.float().contiguous() for p in (g0, b0, g1, b1)]
+        xout, h, stats = nv.ln_add_ln_fwd(x, t, p32[0], p32[1], eps0, p32[2], p32[3], eps1, h_dtype)
+        ctx.save_for_backward(xout, t, stats, p32[0], p32[2])
+        ctx.meta = (x.dtype, t.dtype, g0.dtype)
+        ctx.set_materialize_grads(False)
+        return xout, h
+
+    @staticmethod
+    def backward(ctx, g_xout, g_h):
+        xout, t, stats, g0, g1 = ctx.saved_tensors
+        x_dt, t_dt, p_dt = ctx.meta
+        if g_xout is None and g_h is None:
+            return (None,) * 9
+        g_xout = g_xout.float().contiguous() if g_xout is not None else None
+        g_h = g_h.contiguous() if g_h is not None else None
+        g_x, g_t, dg0, db0, dg1, db1 = nv.ln_add_ln_bwd(g_xout, g_h, xout, t, stats, g0, g1, x_dt, t_dt)
+        return g_x, g_t, dg0.to(p_dt), db0.to(p_dt), None, dg1.to(p_dt), db1.to(p_dt), None, None
+
+
+def ln_add_ln(x, t, ln0, ln1, h_dtype=torch.float32):
+    """x + LayerNorm0(t) and LayerNorm1 of the sum, fused (ln0 / ln1: nn.LayerNorm modules with affine parameters)."""
+    return _LnAddLn.apply(x, t, ln0.weight, ln0.bias, ln0.eps, ln1.weight, ln1.bias, ln1.eps, h_dtype)
 
 
 def add_layer_norm(x, y, rowscale=None, gamma=None, beta=None, eps=1e-5, want_copy=False, h_dtype=torch.float32):

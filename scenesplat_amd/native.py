@@ -334,6 +334,39 @@ def add_layernorm_fwd(x, y, rowscale, gamma, beta, eps, want_xout, want_copy, h_
     return xout, xcopy, h, mean, rstd
 
 
+def ln_add_ln_fwd(x, t, gamma0, beta0, eps0, gamma1, beta1, eps1, h_dtype):
+    """xout = x + LN0(t), h = LN1(xout) in one pass -> (xout f32, h, stats (n,4) f32)."""
+    n, C = x.shape
+    _req(x, None, "x"); _req(t, None, "t", (n, C))
+    for p_, nm in ((gamma0, "gamma0"), (beta0, "beta0"), (gamma1, "gamma1"), (beta1, "beta1")):
+        _req(p_, torch.float32, nm, (C,))
+    dev = x.device
+    xout = torch.empty((n, C), dtype=torch.float32, device=dev)
+    h = torch.empty((n, C), dtype=h_dtype, device=dev)
+    stats = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    check(lib().ss_ln_add_ln_fwd(_p(x), _dt(x), _p(t), _dt(t), _p(gamma0), _p(beta0), float(eps0), _p(gamma1), _p(beta1), float(eps1),
+                                 _p(xout), _p(h), _dt(h), _p(stats), n, C, _stream()), "ss_ln_add_ln_fwd")
+    return xout, h, stats
+
+
+def ln_add_ln_bwd(g_xout, g_h, xout, t, stats, gamma0, gamma1, gx_dtype, gt_dtype):
+    """-> (g_x, g_t, dgamma0, dbeta0, dgamma1, dbeta1)"""
+    n, C = xout.shape
+    dev = xout.device
+    if g_xout is not None:
+        _req(g_xout, torch.float32, "g_xout", (n, C))
+    if g_h is not None:
+        _req(g_h, None, "g_h", (n, C))
+    g_x = torch.empty((n, C), dtype=gx_dtype, device=dev)
+    g_t = torch.empty((n, C), dtype=gt_dtype, device=dev)
+    nb = lib().ss_add_layernorm_bwd_blocks(n)
+    part = torch.empty((4, nb, C), dtype=torch.float32, device=dev)
+    check(lib().ss_ln_add_ln_bwd(_p(g_xout), _p(g_h), _dt(g_h), _p(xout), _p(t), _dt(t), _p(stats), _p(gamma0), _p(gamma1), _p(g_x),
+                                 _dt(g_x), _p(g_t), _dt(g_t), _p(part), n, C, nb, _stream()), "ss_ln_add_ln_bwd")
+    red = part.sum(1)
+    return g_x, g_t, red[0], red[1], red[2], red[3]
+
+
 def add_layernorm_bwd(g_xout, g_xcopy, g_h, v, mean, rstd, gamma, rowscale, gx_dtype, gy_dtype):
     """-> (g_x | None, g_y | None, dgamma | None, dbeta | None)"""
     ref = g_h if g_h is not None else (g_xout if g_xout is not None else g_xcopy)

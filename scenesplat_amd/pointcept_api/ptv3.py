@@ -142,8 +142,11 @@ class Block(PointModule):
         hdt = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
         ln0, ln1, ln2 = self.cpe[2], self.norm1[0], self.norm2[0]
         t = _lin(self.cpe[1], self.cpe[0](conv_in, level))
-        t = SF.layer_norm(t, ln0.weight, ln0.bias, ln0.eps)
-        x, h, _ = SF.add_layer_norm(x, t, None, ln1.weight, ln1.bias, ln1.eps, False, hdt)
+        if RUNTIME.get("fuse_ln_seam", True) and x.shape[1] % 4 == 0 and x.shape[1] <= 1024:
+            x, h = SF.ln_add_ln(x, t, ln0, ln1, hdt)           # x += LN0(t); h = LN1(x): one pass
+        else:
+            t = SF.layer_norm(t, ln0.weight, ln0.bias, ln0.eps)
+            x, h, _ = SF.add_layer_norm(x, t, None, ln1.weight, ln1.bias, ln1.eps, False, hdt)
         x, h, _ = SF.add_layer_norm(x, self.attn(h, level), self._row_scale(x), ln2.weight, ln2.bias, ln2.eps, False, hdt)
         x, _, xb = SF.add_layer_norm(x, self.mlp(h), self._row_scale(x), None, None, 0.0, want_copy, hdt)
         return x, xb

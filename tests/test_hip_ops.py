@@ -491,3 +491,35 @@ def test_segment_minmax_against_oracle(reduce, dtype):
     cot = torch.randn(coarse.n, C, generator=g).to(dtype)
     y.backward(cot.cuda()); yo.backward(cot.float())
     assert torch.equal(xg.grad.float().cpu(), xo.grad.to(dtype).float())
+
+
+@pytest.mark.parametrize("C,xdt,tdt,hdt", [(32, torch.float32, torch.bfloat16, torch.bfloat16), (768, torch.float32, torch.bfloat16, torch.bfloat16),
+                                           (260, torch.float32, torch.float32, torch.float32), (1024, torch.bfloat16, torch.bfloat16, torch.float32)])
+def test_fused_ln_add_ln_against_torch(C, xdt, tdt, hdt):
+    """x + LN0(t) -> LN1 in one kernel each way vs the torch composition in fp32 (same rounded inputs)."""
+    from scenesplat_amd import functional as SF
+    g = torch.Generator().manual_seed(C)
+    n = 777
+    x = torch.randn(n, C, generator=g).to(xdt); t = (torch.randn(n, C, generator=g) * 2 + 0.5).to(tdt)
+    ln0, ln1 = torch.nn.LayerNorm(C, eps=1e-5), torch.nn.LayerNorm(C, eps=1e-5)
+    for ln in (ln0, ln1):
+        ln.weight.data = torch.randn(C, generator=g) * 0.5 + 1.0; ln.bias.data = torch.randn(C, generator=g) * 0.3
+    cx, ch = torch.randn(n, C, generator=g), torch.randn(n, C, generator=g).to(hdt)
+    # reference in fp32
+    xr, tr = x.float().clone().requires_grad_(True), t.float().clone().requires_grad_(True)
+    xo_r = xr + ln0(tr); h_r = ln1(xo_r)
+    ((xo_r * cx).sum() + (h_r * ch.float()).sum()).backward()
+    ref = [xo_r, h_r, xr.grad, tr.grad, ln0.weight.grad.clone(), ln0.bias.grad.clone(), ln1.weight.grad.clone(), ln1.bias.grad.clone()]
+    for ln in (ln0, ln1):
+        ln.zero_grad()
+    l0, l1 = ln0.cuda(), ln1.cuda()
+    xg, tg = x.cuda().requires_grad_(True), t.cuda().requires_grad_(True)
+    xo, h = SF.ln_add_ln(xg, tg, l0, l1, hdt)
+    assert xo.dtype == torch.float32 and h.dtype == hdt
+    torch.autograd.backward([xo, h], [cx.cuda(), ch.cuda()])
+    got = [xo, h, xg.grad, tg.grad, l0.weight.grad, l0.bias.grad, l1.weight.grad, l1.bias.grad]
+    lo = hdt == torch.bfloat16 or xdt == torch.bfloat16 or tdt == torch.bfloat16
+    for i, (a, b) in enumerate(zip(got, ref)):
+        tol = 2e-2 if (lo and i in (1, 2, 3)) else 2e-4
+        err = (a.float().cpu() - b.detach()).abs().max().item() / max(1.0, b.abs().max().item())
+        assert err < tol, (i, err)
