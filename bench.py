@@ -29,8 +29,8 @@ MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n-side", type=int, default=256, help="room side; 256 -> 102,400 Gaussians")
     ap.add_argument("--fixture", default="room", choices=["room", "uniform"],
                     help="room = the metric's workload (SURVEY 8d); uniform = the sparse stress fixture (not the metric)")
@@ -198,12 +198,25 @@ def main():
         t_ = time.perf_counter(); step(); torch.cuda.synchronize()
         log("warmup step %d: %.1f ms" % (i, (time.perf_counter() - t_) * 1e3))
     torch.cuda.synchronize()
+    if os.environ.get("SS_BENCH_GC", "freeze") == "freeze":
+        # one full collection now, then keep the survivors out of later generation-2 scans: a step allocates ~10^5
+        # Python objects (autograd nodes, ctypes wrappers) and an untimely full collection costs ~50 ms
+        import gc
+        gc.collect(); gc.freeze()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if os.environ.get("SS_BENCH_PER_STEP") == "1":      # DIAGNOSTIC: a device sync per step (perturbs the pipeline)
+        for i in range(args.steps):
+            t_ = time.perf_counter(); step(); torch.cuda.synchronize()
+            ms_ = torch.cuda.memory_stats()
+            log("step %d: %.1f ms  reserved %.1f GB  segments %d  device_allocs %d" % (
+                i, (time.perf_counter() - t_) * 1e3, torch.cuda.memory_reserved() / 2**30, ms_.get("segment.all.current", 0),
+                ms_.get("num_device_alloc", 0)))
+    else:
+        for _ in range(args.steps):
+            step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -339,6 +339,11 @@ class Trainer(TrainerBase):
             self.before_epoch()
             for self.comm_info["iter"], self.comm_info["input_dict"] in self.data_iterator:
                 self.before_step(); self.run_step(); self.after_step()
+                if self.comm_info["iter"] == 2 and self.epoch == self.start_epoch and getattr(self.cfg, "gc_freeze", True):
+                    # a step allocates ~10^5 Python objects (autograd nodes, ctypes wrappers); an untimely full
+                    # collection over the long-lived model objects stalls the enqueue thread for ~50 ms
+                    import gc
+                    gc.collect(); gc.freeze()
             self.after_epoch()
         self.after_train()
 
