@@ -281,21 +281,21 @@ k_ln_add_ln_fwd(const void* __restrict__ x, int x_dt, const void* __restrict__ t
   }
 
 template <int IT>
-__global__ void __launch_bounds__(LN_THREADS)
+__global__ void __launch_bounds__(LN_THREADS, (IT <= 3 ? 4 : 2))      // <= 128 VGPRs at C <= 768: 4 waves / SIMD for an HBM-bound kernel
 k_ln_add_ln_bwd(const float* __restrict__ g_xout, const void* __restrict__ g_h, int gh_dt, const float* __restrict__ xout,
                 const void* __restrict__ t, int t_dt, const float* __restrict__ stats, const float* __restrict__ gamma0,
                 const float* __restrict__ gamma1, void* __restrict__ g_x, int gx_dt, void* __restrict__ g_t, int gt_dt,
                 float* __restrict__ part /* [4][nblocks][C]: dgamma0 dbeta0 dgamma1 dbeta1 */, int64_t n, int C) {
-  __shared__ float red[4][LN_THREADS / 64][IT * 4][64];
+  __shared__ float red[2][LN_THREADS / 64][IT * 4][64];   // two rounds of two partial arrays: 24 KB at C = 768 (48 KB capped the kernel at 3 waves / SIMD)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int waves_total = gridDim.x * (LN_THREADS / 64);
-  float4 dg0[IT], db0[IT], dg1[IT], db1[IT], gm0[IT], gm1[IT];
+  // the two gamma vectors live in LDS (6 KB at C = 768), not in 24 VGPRs: the kernel is HBM-bound and needs the waves
+  __shared__ __attribute__((aligned(16))) float gam[2][IT * 256];
+  for (int j = threadIdx.x; j < IT * 256; j += LN_THREADS) { gam[0][j] = j < C ? gamma0[j] : 0.f; gam[1][j] = j < C ? gamma1[j] : 0.f; }
+  __syncthreads();
+  float4 dg0[IT], db0[IT], dg1[IT], db1[IT];
 #pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    dg0[i] = make_float4(0.f, 0.f, 0.f, 0.f); db0[i] = dg0[i]; dg1[i] = dg0[i]; db1[i] = dg0[i]; gm0[i] = dg0[i]; gm1[i] = dg0[i];
-    int j = i * 256 + lane * 4;
-    if (j < C) { gm0[i] = *reinterpret_cast<const float4*>(gamma0 + j); gm1[i] = *reinterpret_cast<const float4*>(gamma1 + j); }
-  }
+  for (int i = 0; i < IT; ++i) { dg0[i] = make_float4(0.f, 0.f, 0.f, 0.f); db0[i] = dg0[i]; dg1[i] = dg0[i]; db1[i] = dg0[i]; }
   for (int64_t row = (int64_t)blockIdx.x * (LN_THREADS / 64) + wave; row < n; row += waves_total) {
     const float4 st = *reinterpret_cast<const float4*>(stats + row * 4);
     float4 xh[IT], gy[IT], gv[IT];
@@ -308,7 +308,8 @@ k_ln_add_ln_bwd(const float* __restrict__ g_xout, const void* __restrict__ g_h, 
         float4 a = *reinterpret_cast<const float4*>(xout + row * C + j), g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g_h) g = ln_ld4(g_h, gh_dt, row * C + j);
         xh[i] = make_float4((a.x - st.z) * st.w, (a.y - st.z) * st.w, (a.z - st.z) * st.w, (a.w - st.z) * st.w);
-        gy[i] = make_float4(g.x * gm1[i].x, g.y * gm1[i].y, g.z * gm1[i].z, g.w * gm1[i].w);
+        const float4 gm1 = *reinterpret_cast<const float4*>(&gam[1][j]);
+        gy[i] = make_float4(g.x * gm1.x, g.y * gm1.y, g.z * gm1.z, g.w * gm1.w);
         dg1[i].x += g.x * xh[i].x; dg1[i].y += g.y * xh[i].y; dg1[i].z += g.z * xh[i].z; dg1[i].w += g.w * xh[i].w;
         db1[i].x += g.x; db1[i].y += g.y; db1[i].z += g.z; db1[i].w += g.w;
       }
@@ -332,7 +333,8 @@ k_ln_add_ln_bwd(const float* __restrict__ g_xout, const void* __restrict__ g_h, 
       if (j < C) {
         float4 a = ln_ld4(t, t_dt, row * C + j);
         xh[i] = make_float4((a.x - st.x) * st.y, (a.y - st.x) * st.y, (a.z - st.x) * st.y, (a.w - st.x) * st.y);
-        gy[i] = make_float4(gv[i].x * gm0[i].x, gv[i].y * gm0[i].y, gv[i].z * gm0[i].z, gv[i].w * gm0[i].w);
+        const float4 gm0 = *reinterpret_cast<const float4*>(&gam[0][j]);
+        gy[i] = make_float4(gv[i].x * gm0.x, gv[i].y * gm0.y, gv[i].z * gm0.z, gv[i].w * gm0.w);
         dg0[i].x += gv[i].x * xh[i].x; dg0[i].y += gv[i].y * xh[i].y; dg0[i].z += gv[i].z * xh[i].z; dg0[i].w += gv[i].w * xh[i].w;
         db0[i].x += gv[i].x; db0[i].y += gv[i].y; db0[i].z += gv[i].z; db0[i].w += gv[i].w;
       }
@@ -345,26 +347,29 @@ k_ln_add_ln_bwd(const float* __restrict__ g_xout, const void* __restrict__ g_h, 
     }
   }
 #pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    red[0][wave][i * 4 + 0][lane] = dg0[i].x; red[0][wave][i * 4 + 1][lane] = dg0[i].y; red[0][wave][i * 4 + 2][lane] = dg0[i].z; red[0][wave][i * 4 + 3][lane] = dg0[i].w;
-    red[1][wave][i * 4 + 0][lane] = db0[i].x; red[1][wave][i * 4 + 1][lane] = db0[i].y; red[1][wave][i * 4 + 2][lane] = db0[i].z; red[1][wave][i * 4 + 3][lane] = db0[i].w;
-    red[2][wave][i * 4 + 0][lane] = dg1[i].x; red[2][wave][i * 4 + 1][lane] = dg1[i].y; red[2][wave][i * 4 + 2][lane] = dg1[i].z; red[2][wave][i * 4 + 3][lane] = dg1[i].w;
-    red[3][wave][i * 4 + 0][lane] = db1[i].x; red[3][wave][i * 4 + 1][lane] = db1[i].y; red[3][wave][i * 4 + 2][lane] = db1[i].z; red[3][wave][i * 4 + 3][lane] = db1[i].w;
-  }
-  __syncthreads();
-  {
-    const int q = wave;                            // wave q reduces partial array q
+  for (int round = 0; round < 2; ++round) {
+    if (round) __syncthreads();                    // round 0's reads are done
 #pragma unroll
-    for (int i = 0; i < IT; ++i)
+    for (int i = 0; i < IT; ++i) {
+      const float4 a = round ? dg1[i] : dg0[i], b = round ? db1[i] : db0[i];
+      red[0][wave][i * 4 + 0][lane] = a.x; red[0][wave][i * 4 + 1][lane] = a.y; red[0][wave][i * 4 + 2][lane] = a.z; red[0][wave][i * 4 + 3][lane] = a.w;
+      red[1][wave][i * 4 + 0][lane] = b.x; red[1][wave][i * 4 + 1][lane] = b.y; red[1][wave][i * 4 + 2][lane] = b.z; red[1][wave][i * 4 + 3][lane] = b.w;
+    }
+    __syncthreads();
+    if (wave < 2) {                                // wave q reduces partial array 2*round + q
+      const int q = wave;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        int j = i * 256 + lane * 4 + e;
-        if (j < C) {
-          float a = 0.f;
-          for (int w = 0; w < LN_THREADS / 64; ++w) a += red[q][w][i * 4 + e][lane];
-          part[((int64_t)q * gridDim.x + blockIdx.x) * C + j] = a;
+      for (int i = 0; i < IT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int j = i * 256 + lane * 4 + e;
+          if (j < C) {
+            float acc = 0.f;
+            for (int w = 0; w < LN_THREADS / 64; ++w) acc += red[q][w][i * 4 + e][lane];
+            part[((int64_t)(2 * round + q) * gridDim.x + blockIdx.x) * C + j] = acc;
+          }
         }
-      }
+    }
   }
 }
 #undef LN_ROW_BWD
