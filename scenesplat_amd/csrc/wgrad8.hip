@@ -4,7 +4,7 @@
 //
 //   GATHER = true   spconv.SubMConv3d weight gradient (ptv3:278-284): row_tap(i) = nbr[tap][i] (pair skipped when
 //                   missing); per tap only the ACTIVE 64-site blocks (ss_subm_block_lists) are walked, split over
-//                   gridDim.z workgroups
+//                   `nshares` workgroups
 //   GATHER = false  nn.Linear weight gradient dW = dy^T x: taps = 1, row(i) = i, every block active
 //
 // Both operands are [site][channel]-major, i.e. K-strided for the MFMA.  The LDS images stay plain [site][256 B]
@@ -54,18 +54,23 @@ __global__ void __launch_bounds__(512)
 k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY, const int32_t* __restrict__ nbr,
          const int32_t* __restrict__ rowperm, const int32_t* __restrict__ blk_count, const int32_t* __restrict__ blk_list,
          float* __restrict__ dW, float* __restrict__ dbias, int n, int Cin, int Cout, int taps, int ntn, int nblocks_total,
-         int min_per) {
+         int min_per, int ntiles, int nshares) {
   __shared__ __attribute__((aligned(16))) char smem[GATHER ? W8_LDS_BYTES : 2 * W8_BUF];
   int32_t* isite_s = reinterpret_cast<int32_t*>(smem + W8_OFF_ISITE);
   int32_t* jsite_s = reinterpret_cast<int32_t*>(smem + W8_OFF_JSITE);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 15, g = lane >> 4;
   const int wr = wave >> 2, wc = wave & 3;
-  const int m0 = (blockIdx.x / ntn) * 256, n0 = (blockIdx.x % ntn) * 256;      // Cout, Cin origins
-  const int tap = blockIdx.y;
+  // ids in (share, tap, tile) order, tile fastest: the tiles of one (tap, share) -- which stream the SAME site rows -- are
+  // dealt round-robin over the XCDs.  Measured: giving them to ONE XCD (to share its L2) is 20-45 % SLOWER (768 -> 768
+  // Linear 191 -> 232 us, conv dec0 1.20 -> 1.64 ms): eight L2s and the Infinity Cache serve the re-reads better than one.
+  const int L = blockIdx.x;
+  const int tile = L % ntiles, group = L / ntiles;                             // group = share * taps + tap
+  const int tap = group % taps, share = group / taps;
+  const int m0 = (tile / ntn) * 256, n0 = (tile % ntn) * 256;                  // Cout, Cin origins
   const int cnt = GATHER ? blk_count[tap] : nblocks_total;
   // a share is at least min_per K-tiles (the 256 KiB fp32-atomic epilogue is paid per share); surplus workgroups exit
-  const int per = max((cnt + (int)gridDim.z - 1) / (int)gridDim.z, min_per);
-  const int beg = blockIdx.z * per, end = min(cnt, beg + per);
+  const int per = max((cnt + nshares - 1) / nshares, min_per);
+  const int beg = share * per, end = min(cnt, beg + per);
   if (end <= beg) return;
   const int32_t* list = GATHER ? blk_list + (int64_t)tap * nblocks_total : nullptr;
 
@@ -81,7 +86,7 @@ k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict_
 
   // column sums of dout (the bias gradient) ride along in the workgroups of the first Cin tile: wave column wc adds
   // its 16-channel group mi = wc of both A halves with an all-ones B fragment (4 extra MFMAs per K-tile)
-  const bool do_bias = !GATHER && dbias != nullptr && (blockIdx.x % ntn) == 0;
+  const bool do_bias = !GATHER && dbias != nullptr && (tile % ntn) == 0;
   f32x4_t accb[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
   w8_bf8_t ones;
   {
@@ -306,9 +311,9 @@ extern "C" int ss_subm_conv_wgrad_pipe(const void* in, const void* dout, const i
   if (env_per == -2) { const char* e = getenv("SS_WGRAD_MINPER"); env_per = e ? atoi(e) : -1; }
   int min_per = env_per > 0 ? env_per : w8_min_per((int64_t)tm * tn * ((taps + 2) / 3), (int64_t)nblocks * 7 / 10);
   int splits = ss_div_up(nblocks, min_per);
-  dim3 g(tm * tn, taps, splits);
+  dim3 g((unsigned)((int64_t)taps * splits * tm * tn));
   SS_LAUNCH((k_wgrad8<true>), g, dim3(512), 0, stream, (const unsigned short*)in, (const unsigned short*)dout, nbr, rowperm,
-            blk_count, blk_list, dweight, (float*)nullptr, (int)n, cin, cout, taps, tn, nblocks, min_per);
+            blk_count, blk_list, dweight, (float*)nullptr, (int)n, cin, cout, taps, tn, nblocks, min_per, tm * tn, splits);
   return SS_OK;
 }
 
@@ -326,9 +331,9 @@ extern "C" int ss_linear_wgrad(const void* x, const void* dy, float* dweight, fl
   if (env_per <= 0 && min_per < 8) min_per = 8;
   if (min_per > nblocks) min_per = nblocks;
   int splits = ss_div_up(nblocks, min_per);
-  dim3 g(tm * tn, 1, splits);
+  dim3 g((unsigned)(splits * tm * tn));
   SS_LAUNCH((k_wgrad8<false>), g, dim3(512), 0, stream, (const unsigned short*)x, (const unsigned short*)dy,
             (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, dweight,
-            dbias, (int)m, k_in, n_out, 1, tn, nblocks, min_per);
+            dbias, (int)m, k_in, n_out, 1, tn, nblocks, min_per, tm * tn, splits);
   return SS_OK;
 }
