@@ -476,8 +476,13 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
 #ifndef FA_BQ2
 #define FA_BQ2 64     // queries per step: two 32-query halves between barriers
 #endif
+#ifndef FA_DKV_WAVES
+#define FA_DKV_WAVES 4      // waves (32 keys each) per dK/dV workgroup
+#endif
+#define DKV_THREADS (64 * FA_DKV_WAVES)
+#define DKV_BKEYS (FA_WQ * FA_DKV_WAVES)
 template <int D>
-__global__ void __launch_bounds__(FA_THREADS, FA_BWD_MIN_BLOCKS)
+__global__ void __launch_bounds__(DKV_THREADS, (FA_DKV_WAVES == 4 ? FA_BWD_MIN_BLOCKS : 1))
 k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ dout,
                     const float* __restrict__ lse, const float* __restrict__ delta, const int32_t* __restrict__ gidx,
                     const int32_t* __restrict__ sidx, const int32_t* __restrict__ win_start,
@@ -485,7 +490,7 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
                     int kchunks) {
   using A = ACfg<D>;
   constexpr int TOT = 2 * FA_BQ2 * A::CH;                     // 16-B chunks per (Q, dO) tile
-  constexpr int NLD = (TOT + FA_THREADS - 1) / FA_THREADS;
+  constexpr int NLD = (TOT + DKV_THREADS - 1) / DKV_THREADS;
   constexpr int RIMG = FA_BQ2 * A::ROWB, TIMG = FA_BQ2 * A::TRB;
   constexpr int BUF = 2 * RIMG + 2 * TIMG + 2 * FA_BQ2 * 4;   // Q row, dO row, Q tr, dO tr, lse2[32], delta[32]
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
@@ -494,14 +499,14 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int kc = lid % kchunks; const int t_ = lid / kchunks; const int h = t_ % H; const int w = t_ / H;
   const int p0 = win_start[w], L = win_start[w + 1] - p0;
-  const int k0 = kc * FA_BQ;
+  const int k0 = kc * DKV_BKEYS;
   if (k0 >= L) return;
-  for (int i = tid; i < L; i += FA_THREADS) { gidx_s[i] = gidx[p0 + i]; sidx_s[i] = sidx[p0 + i]; }
+  for (int i = tid; i < L; i += DKV_THREADS) { gidx_s[i] = gidx[p0 + i]; sidx_s[i] = sidx[p0 + i]; }
   __syncthreads();
   const int64_t C3 = 3 * (int64_t)C;
   const float c2 = scale * 1.44269504088896340736f;
   if (A::CHP > A::CH) {
-    for (int e = tid; e < 4 * FA_BQ2 * (A::CHP - A::CH); e += FA_THREADS) {
+    for (int e = tid; e < 4 * FA_BQ2 * (A::CHP - A::CH); e += DKV_THREADS) {
       int img = e / (FA_BQ2 * (A::CHP - A::CH)); int r = (e / (A::CHP - A::CH)) % FA_BQ2; int ch = A::CH + e % (A::CHP - A::CH);
       char* base = smem + (img >> 1) * BUF + (img & 1) * RIMG;
       *reinterpret_cast<uint4*>(base + row_img_off<D>(r, ch)) = make_uint4(0, 0, 0, 0);
@@ -537,7 +542,7 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
     uint4 (&stage)[NLD] = st.v; float& st_l = st.l; float& st_d = st.d;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      int c = i * FA_THREADS + tid;
+      int c = i * DKV_THREADS + tid;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (c < TOT) {
         int second = c >= FA_BQ2 * A::CH;
@@ -561,7 +566,7 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
     char* base = smem + b * BUF;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      int c = i * FA_THREADS + tid;
+      int c = i * DKV_THREADS + tid;
       if (c < TOT) {
         int second = c >= FA_BQ2 * A::CH;
         int cc = second ? c - FA_BQ2 * A::CH : c;
@@ -698,12 +703,14 @@ int ss_attn_bwd_mfma(const void* qkv, const void* dout, const void* out, const f
   if ((C & 7) || max_window <= 0 || max_window > FA_IDX_CAP) return SS_ERR_ARG;
   const int chunks = (max_window + FA_BQ - 1) / FA_BQ;
   dim3 g((unsigned)(W * H * chunks)), b(FA_THREADS);
+  const int chunks2 = (max_window + DKV_BKEYS - 1) / DKV_BKEYS;
+  dim3 g2((unsigned)(W * H * chunks2)), b2(DKV_THREADS);
   const unsigned short* q = (const unsigned short*)qkv; const unsigned short* go = (const unsigned short*)dout;
   unsigned short* dq = (unsigned short*)dqkv; unsigned short* ex = (unsigned short*)extra;
 #define SS_MB_CASE(DD)                                                                                              \
   case DD:                                                                                                          \
     SS_LAUNCH((k_attn_bwd_dq_mfma<DD>), g, b, 0, st, q, go, (const unsigned short*)out, lse, delta, gidx, sidx, win_start, dq, C, H, scale, chunks); \
-    SS_LAUNCH((k_attn_bwd_dkv_mfma<DD>), g, b, 0, st, q, go, lse, (const float*)delta, gidx, sidx, win_start, dq, ex, C, H, scale, chunks); \
+    SS_LAUNCH((k_attn_bwd_dkv_mfma<DD>), g2, b2, 0, st, q, go, lse, (const float*)delta, gidx, sidx, win_start, dq, ex, C, H, scale, chunks2); \
     break;
   switch (D) {
     SS_MB_CASE(16) SS_MB_CASE(32) SS_MB_CASE(48) SS_MB_CASE(64)
