@@ -523,3 +523,25 @@ def test_fused_ln_add_ln_against_torch(C, xdt, tdt, hdt):
         tol = 2e-2 if (lo and i in (1, 2, 3)) else 2e-4
         err = (a.float().cpu() - b.detach()).abs().max().item() / max(1.0, b.abs().max().item())
         assert err < tol, (i, err)
+
+
+def test_window_attention_long_window_falls_back_to_simt_kernels():
+    """Windows longer than the MFMA kernels' LDS index copy (2048 rows) run on the SIMT kernels even when the caller asks
+    for the MFMA implementation: forward and backward must agree with an explicit SIMT call (bf16 in both)."""
+    from scenesplat_amd import functional as SF, native as nv
+    from scenesplat_amd.plan import build_plan
+    g = torch.Generator().manual_seed(9)
+    n, K, H, d = 5200, 4096, 2, 16
+    gc = torch.stack([torch.randperm(n, generator=g), torch.zeros(n, dtype=torch.long), torch.zeros(n, dtype=torch.long)], 1)
+    plan = build_plan(gc.cuda(), torch.tensor([n]).cuda(), ("z",), ())
+    win = plan.levels[0].window(0, K)
+    assert win.max_window == K
+    qkv = torch.randn(n, 3 * H * d, generator=g).to(torch.bfloat16).cuda()
+    cot = torch.randn(n, H * d, generator=g).to(torch.bfloat16).cuda()
+    res = []
+    for impl in (nv.ATTN_MFMA, nv.ATTN_SIMT):
+        q = qkv.clone().requires_grad_(True)
+        o = SF.window_attention(q, win, H, d ** -0.5, impl)
+        o.backward(cot)
+        res.append((o.detach().float(), q.grad.float()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
