@@ -84,6 +84,11 @@ int ss_window_attn_bwd(const void* qkv, const void* out, const void* dout, const
 int ss_subm_rulebook(const int32_t* grid_coord, const int32_t* batch, int64_t n, int depth,
                      const int64_t* zkeys_sorted, const int32_t* zorder, int swap_xy, int kernel_size, int32_t* nbr,
                      ss_stream_t stream);
+/* same table through an open-addressing hash of the voxel keys (no sorted keys needed); workspace >= 12 *
+ * ss_subm_rulebook_table_size(n) bytes */
+int64_t ss_subm_rulebook_table_size(int64_t n);
+int ss_subm_rulebook_hashed(const int32_t* grid_coord, const int32_t* batch, int64_t n, int depth, int kernel_size, int32_t* nbr,
+                            void* workspace, size_t workspace_bytes, ss_stream_t stream);
 
 /* bf16 MFMA implicit GEMM.  in (n,cin) bf16; weight (cout,taps,cin) bf16 (the reference's
  * (Cout,k,k,k,Cin) layout flattened); bias (cout) f32 or NULL; rowperm (n) = site walk order (z-order)

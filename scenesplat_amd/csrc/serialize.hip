@@ -451,6 +451,68 @@ extern "C" int ss_subm_rulebook(const int32_t* grid_coord, const int32_t* batch,
   return SS_OK;
 }
 
+// Hashed rulebook: the same table as ss_subm_rulebook from an open-addressing hash of the voxel keys (load <= 0.5,
+// linear probing, ~1.3 probes per lookup) instead of a 17-step binary search per (site, tap): the 125-tap stem rulebook
+// of a 102,400-site level took ~0.4 ms per step.  Duplicate voxels resolve to the lowest row (atomicMin), as the sorted
+// lookup does.  workspace = T x (8 + 4) bytes, T = ss_subm_rulebook_table_size(n).
+__device__ __forceinline__ uint32_t rb_hash(uint64_t key, int log2t) { return (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> (64 - log2t)); }
+__global__ void k_rulebook_insert(const int32_t* __restrict__ gc, const int32_t* __restrict__ batch, int64_t n, int depth,
+                                  unsigned long long* __restrict__ tkeys, int32_t* __restrict__ tvals, int log2t) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t key = morton3(gc[3 * i], gc[3 * i + 1], gc[3 * i + 2]) | (((uint64_t)(uint32_t)batch[i]) << (3 * depth));
+  const uint32_t mask = (1u << log2t) - 1u;
+  uint32_t slot = rb_hash(key, log2t);
+  for (;;) {
+    unsigned long long old = atomicCAS(&tkeys[slot], ~0ULL, (unsigned long long)key);
+    if (old == ~0ULL || old == (unsigned long long)key) { atomicMin(&tvals[slot], (int32_t)i); return; }
+    slot = (slot + 1) & mask;
+  }
+}
+__global__ void k_rulebook_lookup(const int32_t* __restrict__ gc, const int32_t* __restrict__ batch, int64_t n, int depth,
+                                  const unsigned long long* __restrict__ tkeys, const int32_t* __restrict__ tvals, int log2t,
+                                  int ksize, int32_t* __restrict__ nbr) {
+  const int taps = ksize * ksize * ksize;
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * taps) return;
+  int t = (int)(gid / n); int64_t i = gid - (int64_t)t * n;
+  int h = ksize >> 1;
+  int iz = t % ksize, iy = (t / ksize) % ksize, ix = t / (ksize * ksize);
+  int x = gc[3 * i] + ix - h, y = gc[3 * i + 1] + iy - h, z = gc[3 * i + 2] + iz - h;
+  int lim = 1 << depth;
+  int32_t res = -1;
+  if (x >= 0 && y >= 0 && z >= 0 && x < lim && y < lim && z < lim) {
+    uint64_t key = morton3(x, y, z) | (((uint64_t)(uint32_t)batch[i]) << (3 * depth));
+    const uint32_t mask = (1u << log2t) - 1u;
+    uint32_t slot = rb_hash(key, log2t);
+    for (;;) {
+      unsigned long long k = tkeys[slot];
+      if (k == (unsigned long long)key) { res = tvals[slot]; break; }
+      if (k == ~0ULL) break;
+      slot = (slot + 1) & mask;
+    }
+  }
+  nbr[gid] = res;
+}
+static int rb_log2t(int64_t n) { int l = 10; while ((1LL << l) < 2 * n) ++l; return l; }
+extern "C" int64_t ss_subm_rulebook_table_size(int64_t n) { return n < 0 ? 0 : (1LL << rb_log2t(n)); }
+extern "C" int ss_subm_rulebook_hashed(const int32_t* grid_coord, const int32_t* batch, int64_t n, int depth, int kernel_size,
+                                       int32_t* nbr, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (n < 0 || (kernel_size != 3 && kernel_size != 5) || depth < 0 || depth > 16 || n >= (1LL << 30)) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  const int l2 = rb_log2t(n);
+  const size_t T = (size_t)1 << l2;
+  if (!workspace || workspace_bytes < T * 12) return SS_ERR_WORKSPACE;
+  unsigned long long* tkeys = (unsigned long long*)workspace;
+  int32_t* tvals = (int32_t*)((char*)workspace + T * 8);
+  if (hipMemsetAsync(tkeys, 0xFF, T * 8, stream) != hipSuccess || hipMemsetAsync(tvals, 0x7F, T * 4, stream) != hipSuccess) return SS_ERR_LAUNCH;
+  SS_LAUNCH(k_rulebook_insert, dim3(ss_div_up(n, 256)), dim3(256), 0, stream, grid_coord, batch, n, depth, tkeys, tvals, l2);
+  int64_t total = n * kernel_size * kernel_size * kernel_size;
+  SS_LAUNCH(k_rulebook_lookup, dim3(ss_div_up(total, 256)), dim3(256), 0, stream, grid_coord, batch, n, depth, tkeys, tvals, l2,
+            kernel_size, nbr);
+  return SS_OK;
+}
+
 // batch[i] = #offsets <= i  (offset2batch, pointcept/models/utils/misc.py:19-23); offsets (B) inclusive ends
 __global__ void k_offsets_to_batch(const int32_t* __restrict__ offsets, int num_batches, int64_t n, int32_t* __restrict__ batch) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

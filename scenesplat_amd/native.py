@@ -143,11 +143,19 @@ def window_index(order_row, offsets, offsets_pad, patch, n_pad):
     return gidx, sidx
 
 
+RULEBOOK_HASHED = True    # hash-table lookups (ss_subm_rulebook_hashed) instead of binary search in the sorted z keys
+
+
 def subm_rulebook(gc32, batch32, depth, zkeys_sorted, zorder, swap_xy, ksize):
     n = gc32.shape[0]
     _req(gc32, torch.int32, "grid_coord", (n, 3)); _req(batch32, torch.int32, "batch", (n,))
-    _req(zkeys_sorted, torch.int64, "zkeys_sorted", (n,)); _req(zorder, torch.int32, "zorder", (n,))
     nbr = torch.empty((ksize ** 3, n), dtype=torch.int32, device=gc32.device)
+    if RULEBOOK_HASHED and n < (1 << 30):
+        ws = _ws(12 * lib().ss_subm_rulebook_table_size(n), gc32.device)
+        check(lib().ss_subm_rulebook_hashed(_p(gc32), _p(batch32), n, int(depth), int(ksize), _p(nbr), _p(ws), ws.numel(), _stream()),
+              "ss_subm_rulebook_hashed")
+        return nbr
+    _req(zkeys_sorted, torch.int64, "zkeys_sorted", (n,)); _req(zorder, torch.int32, "zorder", (n,))
     check(lib().ss_subm_rulebook(_p(gc32), _p(batch32), n, int(depth), _p(zkeys_sorted), _p(zorder), int(swap_xy),
                                  int(ksize), _p(nbr), _stream()), "ss_subm_rulebook")
     return nbr

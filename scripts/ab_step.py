@@ -45,6 +45,8 @@ def setter(on):
             model.__dict__["_draw_row_scales"] = lambda levels, device: None
     elif which == "ln_seam":
         RUNTIME["fuse_ln_seam"] = on
+    elif which == "rb_hash":
+        nv.RULEBOOK_HASHED = on
     elif which == "mask_small":
         import scenesplat_amd.plan as P
         P.CONV_MASK_MIN_SITES = 4096 if on else 16384

@@ -545,3 +545,27 @@ def test_window_attention_long_window_falls_back_to_simt_kernels():
         o.backward(cot)
         res.append((o.detach().float(), q.grad.float()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("dup", [False, True])
+@pytest.mark.parametrize("k", [3, 5])
+def test_rulebook_hashed_equals_sorted_lookup(k, dup, monkeypatch):
+    """ss_subm_rulebook_hashed (hash table) against ss_subm_rulebook (binary search in the sorted z keys): bit-identical
+    tables, including duplicate voxels (lowest row wins) and two batch elements; the latter is pinned on the oracle."""
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.plan import build_plan
+    g = torch.Generator().manual_seed(k + dup)
+    gc = torch.randint(0, 20, (5000, 3), generator=g)
+    if not dup:
+        gc = torch.unique(gc, dim=0)
+        gc = gc[torch.randperm(len(gc), generator=g)]
+    n = len(gc)
+    offs = torch.tensor([n // 3, n])
+    tabs = []
+    for hashed in (False, True):
+        monkeypatch.setattr(nv, "RULEBOOK_HASHED", hashed)
+        plan = build_plan(gc.cuda(), offs.cuda(), ORD, ())
+        tabs.append(plan.levels[0].neighbors(k).cpu())
+    assert torch.equal(tabs[0], tabs[1])
+    batch = np.repeat([0, 1], [n // 3, n - n // 3])
+    assert np.array_equal(tabs[1].numpy(), np.asarray(oops.neighbor_table(gc.numpy(), batch, k)).T)
