@@ -84,6 +84,10 @@ int ss_window_attn_bwd(const void* qkv, const void* out, const void* dout, const
 int ss_subm_rulebook(const int32_t* grid_coord, const int32_t* batch, int64_t n, int depth,
                      const int64_t* zkeys_sorted, const int32_t* zorder, int swap_xy, int kernel_size, int32_t* nbr,
                      ss_stream_t stream);
+/* keys (n) int64 for regrouping the conv walk order: tap-presence mask of site order[p] (taps <= 27 bits) below the coarse
+ * block id p >> coarse_bits; a stable sort of them gives the walk of scenesplat_amd.plan.Level.conv_rowperm */
+int ss_subm_tap_mask_keys(const int32_t* nbr, const int32_t* order, int64_t n, int taps, int coarse_bits, int64_t* keys,
+                          ss_stream_t stream);
 /* same table through an open-addressing hash of the voxel keys (no sorted keys needed); workspace >= 12 *
  * ss_subm_rulebook_table_size(n) bytes */
 int64_t ss_subm_rulebook_table_size(int64_t n);

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "ss_segment_minmax_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_p]),
     "ss_subm_rulebook_table_size": (c_i64, [c_i64]),
     "ss_subm_rulebook_hashed": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p, c_p, ctypes.c_size_t, c_p]),
+    "ss_subm_tap_mask_keys": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p, c_p]),
     "ss_subm_weight_mirror": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "ss_subm_im2col": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i64, c_p]),
     "ss_gemm8_ok": (c_i, [c_i64, c_i, c_i, c_i]),

@@ -513,6 +513,25 @@ extern "C" int ss_subm_rulebook_hashed(const int32_t* grid_coord, const int32_t*
   return SS_OK;
 }
 
+// sort key of the mask-grouped conv walk: key[p] = tapmask(order[p]) | (p >> coarse_bits) << taps, tapmask bit t = site has
+// its tap-t neighbour (taps <= 27)
+__global__ void k_tap_mask_keys(const int32_t* __restrict__ nbr, const int32_t* __restrict__ order, int64_t n, int taps,
+                                int coarse_bits, int64_t* __restrict__ keys) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int64_t i = order ? order[p] : p;
+  uint32_t m = 0;
+  for (int t = 0; t < taps; ++t) m |= (nbr[(int64_t)t * n + i] >= 0 ? 1u : 0u) << t;
+  keys[p] = (int64_t)m | ((p >> coarse_bits) << taps);
+}
+extern "C" int ss_subm_tap_mask_keys(const int32_t* nbr, const int32_t* order, int64_t n, int taps, int coarse_bits,
+                                     int64_t* keys, hipStream_t stream) {
+  if (n < 0 || taps < 1 || taps > 27 || coarse_bits < 0 || coarse_bits > 30) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  SS_LAUNCH(k_tap_mask_keys, dim3(ss_div_up(n, 256)), dim3(256), 0, stream, nbr, order, n, taps, coarse_bits, keys);
+  return SS_OK;
+}
+
 // batch[i] = #offsets <= i  (offset2batch, pointcept/models/utils/misc.py:19-23); offsets (B) inclusive ends
 __global__ void k_offsets_to_batch(const int32_t* __restrict__ offsets, int num_batches, int64_t n, int32_t* __restrict__ batch) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

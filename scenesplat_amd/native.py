@@ -161,6 +161,15 @@ def subm_rulebook(gc32, batch32, depth, zkeys_sorted, zorder, swap_xy, ksize):
     return nbr
 
 
+def subm_tap_mask_keys(nbr, order, coarse_bits):
+    """(taps,n) rulebook + walk order -> (n,) int64 sort keys: tap mask | coarse block id << taps."""
+    taps, n = nbr.shape
+    _req(nbr, torch.int32, "nbr"); _req(order, torch.int32, "order", (n,))
+    keys = torch.empty(n, dtype=torch.int64, device=nbr.device)
+    check(lib().ss_subm_tap_mask_keys(_p(nbr), _p(order), n, taps, int(coarse_bits), _p(keys), _stream()), "ss_subm_tap_mask_keys")
+    return keys
+
+
 def subm_conv_fwd(x, w, bias, nbr, rowperm, out_dtype=torch.bfloat16):
     """x (n,cin) bf16, w (cout,taps,cin) bf16, bias (cout) f32|None, nbr (taps,n) -> (n,cout)."""
     n, cin = x.shape

@@ -120,12 +120,9 @@ class Level:
         rp = base
         if CONV_ORDER == "mask" and self.n >= CONV_MASK_MIN_SITES and self.n < (1 << 30):
             nbr = self.neighbors(3)
-            w = (1 << torch.arange(27, device=nbr.device, dtype=torch.int64)).unsqueeze(1)
-            mask = ((nbr >= 0).to(torch.int64) * w).sum(0)                      # (n,) 27-bit tap mask per site
-            pos = torch.arange(self.n, device=nbr.device, dtype=torch.int64)
-            key = mask[base.long()] | ((pos >> CONV_COARSE_BITS) << 27)
+            key = nv.subm_tap_mask_keys(nbr, base.contiguous(), CONV_COARSE_BITS)
             bits = 27 + max(1, (self.n >> CONV_COARSE_BITS).bit_length())
-            perm, _, _ = nv.argsort_i64(key.unsqueeze(0).contiguous(), bits, want_inverse=False, want_sorted=False)
+            perm, _, _ = nv.argsort_i64(key.unsqueeze(0), bits, want_inverse=False, want_sorted=False)
             rp = base[perm[0].long()].contiguous()
         self._nbr["rowperm"] = rp
         return rp
