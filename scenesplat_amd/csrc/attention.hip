@@ -14,7 +14,8 @@ extern "C" int ss_window_attn_fwd(const void* qkv, const int32_t* gidx, const in
   if (num_windows < 0 || channels <= 0 || num_heads <= 0 || channels % num_heads || n_pad < n) return SS_ERR_ARG;
   if (dtype != SS_F32 && dtype != SS_BF16) return SS_ERR_ARG;
   if (num_windows == 0) return SS_OK;
-  if (impl == SS_ATTN_MFMA && max_window > SS_ATTN_MFMA_MAX_WINDOW) impl = SS_ATTN_SIMT;   // index copy does not fit LDS
+  // the MFMA kernels keep the window's row offsets (16-byte units, 32 bits) in LDS
+  if (impl == SS_ATTN_MFMA && (max_window > SS_ATTN_MFMA_MAX_WINDOW || n * (int64_t)(3 * channels / 8) >= (1LL << 31))) impl = SS_ATTN_SIMT;
   if (impl == SS_ATTN_SIMT)
     return ss_attn_fwd_simt(qkv, gidx, sidx, win_start, num_windows, out, lse, channels, num_heads, scale, dtype, stream);
   if (impl == SS_ATTN_MFMA && dtype == SS_BF16)
@@ -39,7 +40,7 @@ extern "C" int ss_window_attn_bwd(const void* qkv, const void* out, const void* 
   float* delta = (float*)workspace;
   void* extra = (char*)workspace + al256((size_t)n_pad * num_heads * 4);
   int rc = SS_OK;
-  if (impl == SS_ATTN_MFMA && max_window > SS_ATTN_MFMA_MAX_WINDOW) impl = SS_ATTN_SIMT;
+  if (impl == SS_ATTN_MFMA && (max_window > SS_ATTN_MFMA_MAX_WINDOW || n * (int64_t)(3 * channels / 8) >= (1LL << 31))) impl = SS_ATTN_SIMT;
   if (!(impl == SS_ATTN_MFMA && dtype == SS_BF16))      // the MFMA dQ kernel computes delta itself
     rc = ss_attn_delta(out, dout, sidx, delta, n_pad, channels, num_heads, dtype, stream);
   if (rc) return rc;

@@ -107,8 +107,9 @@ __device__ __forceinline__ void tile_load(uint4 (&reg)[NLD], const unsigned shor
     // (K) or multiplied by p = 0 (V), so no zero fill and no divergent branch
     uint4 v = make_uint4(0, 0, 0, 0);
     if ((2 * 64 * CH) % FA_THREADS == 0 || c < 2 * 64 * CH) {
-      int64_t row = gidx_w[min(r0 + r, L - 1)];
-      v = ld16(qkv + row * C3 + (second ? colofs_b : colofs_a) + ch * 8);
+      // gidx_w holds row * (3C / 8): the row's offset in 16-byte units, so the address is one shift-add
+      const uint64_t o16 = (uint32_t)gidx_w[min(r0 + r, L - 1)];
+      v = ld16(reinterpret_cast<const char*>(qkv + (second ? colofs_b : colofs_a) + ch * 8) + (o16 << 4));
     }
     reg[i] = v;
   }
@@ -134,7 +135,7 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
   const int p0 = win_start[w], L = win_start[w + 1] - p0;
   const int q0 = qc * FA_BQ;
   if (q0 >= L) return;
-  for (int i = tid; i < L; i += FA_THREADS) gidx_s[i] = gidx[p0 + i];
+  for (int i = tid; i < L; i += FA_THREADS) gidx_s[i] = (int32_t)((uint32_t)gidx[p0 + i] * (uint32_t)(3 * C >> 3));
   __syncthreads();
   const int64_t C3 = 3 * (int64_t)C;
   const float c2 = scale * 1.44269504088896340736f;
@@ -326,7 +327,7 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
   const int p0 = win_start[w], L = win_start[w + 1] - p0;
   const int q0 = qc * FA_BQ;
   if (q0 >= L) return;
-  for (int i = tid; i < L; i += FA_THREADS) gidx_s[i] = gidx[p0 + i];
+  for (int i = tid; i < L; i += FA_THREADS) gidx_s[i] = (int32_t)((uint32_t)gidx[p0 + i] * (uint32_t)(3 * C >> 3));
   __syncthreads();
   const int64_t C3 = 3 * (int64_t)C;
   const float c2 = scale * 1.44269504088896340736f;
@@ -501,7 +502,11 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
   const int p0 = win_start[w], L = win_start[w + 1] - p0;
   const int k0 = kc * DKV_BKEYS;
   if (k0 >= L) return;
-  for (int i = tid; i < L; i += DKV_THREADS) { gidx_s[i] = gidx[p0 + i]; sidx_s[i] = sidx[p0 + i]; }
+  for (int i = tid; i < L; i += DKV_THREADS) {          // offsets in 16-byte units (row * 3C/8, row * C/8); borrowed slots stay < 0
+    gidx_s[i] = (int32_t)((uint32_t)gidx[p0 + i] * (uint32_t)(3 * C >> 3));
+    int32_t sr = sidx[p0 + i];
+    sidx_s[i] = sr >= 0 ? sr * (C >> 3) : -1;
+  }
   __syncthreads();
   const int64_t C3 = 3 * (int64_t)C;
   const float c2 = scale * 1.44269504088896340736f;
@@ -549,8 +554,8 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
         int cc = second ? c - FA_BQ2 * A::CH : c;
         int r = cc / A::CH, ch = cc - r * A::CH;
         if (qb + r < L) {
-          if (!second) v = ld16(qkv + (int64_t)gidx_s[qb + r] * C3 + h * D + ch * 8);
-          else { int32_t sr = sidx_s[qb + r]; if (sr >= 0) v = ld16(dout + (int64_t)sr * C + h * D + ch * 8); }
+          if (!second) v = ld16(reinterpret_cast<const char*>(qkv + h * D + ch * 8) + ((uint64_t)(uint32_t)gidx_s[qb + r] << 4));
+          else { int32_t sr = sidx_s[qb + r]; if (sr >= 0) v = ld16(reinterpret_cast<const char*>(dout + h * D + ch * 8) + ((uint64_t)(uint32_t)sr << 4)); }
         }
       }
       stage[i] = v;
