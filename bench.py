@@ -194,7 +194,9 @@ def main():
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
-    for i in range(args.warmup):
+    # at least 3 untimed steps before the timed region (allocator pools of both streams, hipBLASLt heuristics, lazy
+    # code-object loads settle within the first three): the W warm-up steps asked for, topped up when W < 3
+    for i in range(max(args.warmup, 3)):
         t_ = time.perf_counter(); step(); torch.cuda.synchronize()
         log("warmup step %d: %.1f ms" % (i, (time.perf_counter() - t_) * 1e3))
     torch.cuda.synchronize()
