@@ -59,6 +59,21 @@ __device__ __forceinline__ bf8_t pack8(f32x4_t a, f32x4_t b) {
   v.z = pack_bf16x2(b[0], b[1]); v.w = pack_bf16x2(b[2], b[3]);
   return as_bf8(v);
 }
+// 8 bf16 (one uint4) times a scalar, rounded back to bf16 (RNE)
+__device__ __forceinline__ uint4 scale_bf16x8(uint4 v, float c) {
+  uint4 r;
+  r.x = pack_bf16x2(__uint_as_float(v.x << 16) * c, __uint_as_float(v.x & 0xffff0000u) * c);
+  r.y = pack_bf16x2(__uint_as_float(v.y << 16) * c, __uint_as_float(v.y & 0xffff0000u) * c);
+  r.z = pack_bf16x2(__uint_as_float(v.z << 16) * c, __uint_as_float(v.z & 0xffff0000u) * c);
+  r.w = pack_bf16x2(__uint_as_float(v.w << 16) * c, __uint_as_float(v.w & 0xffff0000u) * c);
+  return r;
+}
+__device__ __forceinline__ float bf16_round(float x) { return __uint_as_float(pack_bf16x2(x, 0.f) << 16); }
+// x ~= hi + lo with both exactly representable in bf16 (relative error ~2^-17): packed {hi, lo}
+__device__ __forceinline__ unsigned int bf16_hi_lo(float x) {
+  float hi = bf16_round(x);
+  return pack_bf16x2(hi, x - hi);
+}
 __device__ __forceinline__ float xmax4(float v) {   // max over the 4 lane groups (lanes l, l^16, l^32, l^48)
   v = fmaxf(v, __shfl_xor(v, 16, 64));
   return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -84,6 +99,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {   // bijective: bloc
 #define FA_WQ (16 * FA_NT)            // rows (queries / keys) per wave
 #define FA_BQ (FA_WQ * FA_WAVES)      // 256 rows per workgroup
 #define FA_BK 64
+#ifndef FA_FWD_PAD
+#define FA_FWD_PAD 0
+#endif
 #ifndef FA_PREFETCH2
 #define FA_PREFETCH2 0   // 1: two register stages (tile requested two steps ahead); measured neutral, costs 12-18 VGPRs
 #endif
@@ -145,10 +163,17 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
   if (A::CHP > A::CH) {
     for (int e = tid; e < 2 * 64 * (A::CHP - A::CH); e += FA_THREADS) {
       int b = e / (64 * (A::CHP - A::CH)); int r = (e / (A::CHP - A::CH)) % 64; int ch = A::CH + e % (A::CHP - A::CH);
-      *reinterpret_cast<uint4*>(Kbuf(b) + row_img_off<D>(r, ch)) = make_uint4(0, 0, 0, 0);
+      // FA_FWD_PAD: contraction column D carries a constant 1; with the Q side holding -shift there, the MFMA itself
+      // subtracts the softmax shift.  Measured SLOWER in the forward (0.68 -> 0.77 ms at dec0): some query of the wave
+      // sees a new maximum on almost every tile, and that path then pays the subtraction plus the fragment update;
+      // the backward kernels, whose shifts (lse, delta) are known up front, keep the trick.
+      *reinterpret_cast<uint4*>(Kbuf(b) + row_img_off<D>(r, ch)) = make_uint4((FA_FWD_PAD && ch == A::CH) ? 0x3F80u : 0u, 0, 0, 0);
     }
   }
-  // Q fragments (B operand of S^T = K Q^T): lane holds Q[q = lq][d = 32ks + 8g .. +7]
+  constexpr bool PAD = FA_FWD_PAD && (A::CHP > A::CH);   // free contraction columns (d = 16, 48)
+  constexpr int PADKS = D / 32, PADG = (D % 32) / 8; // fragment position of contraction column D
+  // Q fragments (B operand of S^T = K Q^T): lane holds Q[q = lq][d = 32ks + 8g .. +7]; with PAD they are pre-scaled
+  // by scale * log2(e) so that S^T comes out of the MFMA in exp2 units
   bf8_t qf[FA_NT][A::NKS];
   int qslot[FA_NT];
 #pragma unroll
@@ -161,6 +186,7 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
       int d0 = 32 * ks + 8 * g;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (row >= 0 && d0 < D) v = ld16(qkv + row * C3 + h * D + d0);
+      if (PAD) v = scale_bf16x8(v, c2);
       qf[qt][ks] = as_bf8(v);
     }
   }
@@ -172,7 +198,7 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
   f32x4_t o[A::NDT][FA_NT], lsum[FA_NT];
 #pragma unroll
   for (int qt = 0; qt < FA_NT; ++qt) {
-    m[qt] = -1e30f; lsum[qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    m[qt] = PAD ? 0.f : -1e30f; lsum[qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};   // PAD: m = current shift in exp2 units
 #pragma unroll
     for (int dt = 0; dt < A::NDT; ++dt) o[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
@@ -232,6 +258,32 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
       mx = xmax4(mx);
+      if (PAD) {
+        // s is already c2 * S - shift (shift = m[qt], a bf16-exact value held in Q's contraction column D).  Only when a
+        // score exceeds the shift (or on the first tile) does the shift move; then this tile pays the subtraction.
+        const bool move = (t == 0) || (mx > 0.f);
+        if (__any(move)) {
+          const float ns = move ? bf16_round(m[qt] + mx) : m[qt];
+          const float dlt = ns - m[qt];
+          const float alpha = __builtin_amdgcn_exp2f(-dlt);
+          lsum[qt] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < A::NDT; ++dt) o[dt][qt] *= alpha;
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kt][qt][r] = __builtin_amdgcn_exp2f(s[kt][qt][r] - dlt);
+          m[qt] = ns;
+          uint4 u = __builtin_bit_cast(uint4, qf[qt][PADKS]);
+          if (g == PADG) u.x = (u.x & 0xffff0000u) | (pack_bf16x2(-ns, 0.f) & 0xffffu);
+          qf[qt][PADKS] = as_bf8(u);
+        } else {
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kt][qt][r] = __builtin_amdgcn_exp2f(s[kt][qt][r]);
+        }
+      } else {
       float mn = fmaxf(m[qt], mx);
       // exact skip: when no lane's running max moved, alpha == 1 for the whole wave
       if (__any(mn > m[qt])) {
@@ -248,6 +300,7 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
         for (int r = 0; r < 4; ++r) {
           s[kt][qt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], c2, -mc));
         }
+      }
     }
     // ---- O^T += V^T P^T ; k index (g, j) of step kk <-> key 32kk + 16(j>>2) + 4g + (j&3)
 #pragma unroll
@@ -284,7 +337,7 @@ k_attn_fwd_mfma(const unsigned short* __restrict__ qkv, const int32_t* __restric
     float lt = __shfl(lsum[qt][0], lq, 64);   // row 0 of the ones tile lives in lane group 0
     int slot = qslot[qt];
     if (slot < L) {
-      if (g == 0) lse[(int64_t)(p0 + slot) * H + h] = m[qt] * scale + __logf(lt);
+      if (g == 0) lse[(int64_t)(p0 + slot) * H + h] = (PAD ? m[qt] * 0.69314718055994530942f : m[qt] * scale) + __logf(lt);
       int32_t srow = sidx[p0 + slot];
       if (srow >= 0) {
         float inv = 1.f / lt;
@@ -335,9 +388,13 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
     for (int e = tid; e < 4 * 64 * (A::CHP - A::CH); e += FA_THREADS) {
       int img = e / (64 * (A::CHP - A::CH)); int r = (e / (A::CHP - A::CH)) % 64; int ch = A::CH + e % (A::CHP - A::CH);
       char* base = smem + (img >> 1) * BUF + (img & 1) * RIMG;
-      *reinterpret_cast<uint4*>(base + row_img_off<D>(r, ch)) = make_uint4(0, 0, 0, 0);
+      // contraction columns D, D+1 of the K and V row images carry 1, 1: the query side holds -(lse, delta) there as
+      // bf16 hi + lo pairs, so S^T comes out as c2*S - lse2 and dP^T as dP - delta (two VALU ops per score saved)
+      *reinterpret_cast<uint4*>(base + row_img_off<D>(r, ch)) = make_uint4(ch == A::CH ? 0x3F803F80u : 0u, 0, 0, 0);
     }
   }
+  constexpr bool PAD = A::CHP > A::CH;
+  constexpr int PADKS = D / 32, PADG = (D % 32) / 8;
   bf8_t qf[FA_NT][A::NKS], gf[FA_NT][A::NKS];
   float lse2[FA_NT], dl[FA_NT];
   int32_t srow[FA_NT];
@@ -357,7 +414,7 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
       uint4 v = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0), o = make_uint4(0, 0, 0, 0);
       if (row >= 0 && d0 < D) v = ld16(qkv + row * C3 + h * D + d0);
       if (srow[qt] >= 0 && d0 < D) { u = ld16(dout + (int64_t)srow[qt] * C + h * D + d0); o = ld16(outp + (int64_t)srow[qt] * C + h * D + d0); }
-      qf[qt][ks] = as_bf8(v); gf[qt][ks] = as_bf8(u);
+      qf[qt][ks] = as_bf8(PAD ? scale_bf16x8(v, c2) : v); gf[qt][ks] = as_bf8(u);
       const unsigned int* uu = reinterpret_cast<const unsigned int*>(&u);
       const unsigned int* uo = reinterpret_cast<const unsigned int*>(&o);
 #pragma unroll
@@ -368,6 +425,10 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
     }
     dl[qt] = xsum4(dsum);
     if (ok && g == 0) delta[(int64_t)(p0 + slot) * H + h] = dl[qt];
+    if (PAD && g == PADG) {
+      uint4 u = __builtin_bit_cast(uint4, qf[qt][PADKS]); u.x = bf16_hi_lo(-lse2[qt]); qf[qt][PADKS] = as_bf8(u);
+      u = __builtin_bit_cast(uint4, gf[qt][PADKS]); u.x = bf16_hi_lo(-dl[qt]); gf[qt][PADKS] = as_bf8(u);
+    }
   }
   f32x4_t dq[A::NDT][FA_NT];
 #pragma unroll
@@ -424,8 +485,9 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
       for (int qt = 0; qt < FA_NT; ++qt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], c2, -lse2[qt]));
-          float ds = p * (dp[kt][qt][r] - dl[qt]);
+          float p, ds;
+          if (PAD) { p = __builtin_amdgcn_exp2f(s[kt][qt][r]); ds = p * dp[kt][qt][r]; }
+          else { p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], c2, -lse2[qt])); ds = p * (dp[kt][qt][r] - dl[qt]); }
           if (tail && kv0 + 16 * kt + 4 * g + r >= L) ds = 0.f;
           s[kt][qt][r] = ds;
         }
@@ -517,6 +579,8 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
       *reinterpret_cast<uint4*>(base + row_img_off<D>(r, ch)) = make_uint4(0, 0, 0, 0);
     }
   }
+  constexpr bool PAD = A::CHP > A::CH;
+  constexpr int PADKS = D / 32, PADG = (D % 32) / 8;
   // K / V fragments as B operands: lane holds K[key = lq][d = 32ks + 8g ..]
   bf8_t kf[FA_NT][A::NKS], vf[FA_NT][A::NKS];
   int kslot[FA_NT];
@@ -530,6 +594,12 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
       int d0 = 32 * ks + 8 * g;
       uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
       if (row >= 0 && d0 < D) { a = ld16(qkv + row * C3 + C + h * D + d0); b = ld16(qkv + row * C3 + 2 * C + h * D + d0); }
+      if (PAD) {
+        // K pre-scaled by scale*log2(e); contraction columns D, D+1 of both fragments carry 1, 1: the streamed Q / dO rows
+        // hold -(lse2) / -(delta) there as bf16 hi + lo, so the MFMAs deliver c2*S - lse2 and dP - delta directly
+        a = scale_bf16x8(a, c2);
+        if (ks == PADKS && g == PADG) { a.x = 0x3F803F80u; b.x = 0x3F803F80u; }
+      }
       kf[kt][ks] = as_bf8(a); vf[kt][ks] = as_bf8(b);
     }
   }
@@ -581,8 +651,13 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
       }
     }
     if (tid < FA_BQ2) {
-      float* f = reinterpret_cast<float*>(base + 2 * RIMG + 2 * TIMG);
-      f[tid] = st_l; f[FA_BQ2 + tid] = st_d;
+      if (PAD) {      // first pad chunk of the row's Q / dO images: {-lse2 hi, lo} / {-delta hi, lo}
+        *reinterpret_cast<uint4*>(base + row_img_off<D>(tid, A::CH)) = make_uint4(bf16_hi_lo(-st_l), 0, 0, 0);
+        *reinterpret_cast<uint4*>(base + RIMG + row_img_off<D>(tid, A::CH)) = make_uint4(bf16_hi_lo(-st_d), 0, 0, 0);
+      } else {
+        float* f = reinterpret_cast<float*>(base + 2 * RIMG + 2 * TIMG);
+        f[tid] = st_l; f[FA_BQ2 + tid] = st_d;
+      }
     }
   };
   const int ntiles = (L + FA_BQ2 - 1) / FA_BQ2;
@@ -620,12 +695,13 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float l2 = fl[32 * hq + 16 * qt + 4 * g + r], dd = fl[FA_BQ2 + 32 * hq + 16 * qt + 4 * g + r];
+        float l2 = 0.f, dd = 0.f;
+        if (!PAD) { l2 = fl[32 * hq + 16 * qt + 4 * g + r]; dd = fl[FA_BQ2 + 32 * hq + 16 * qt + 4 * g + r]; }
 #pragma unroll
         for (int kt = 0; kt < FA_NT; ++kt) {
-          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][kt][r], c2, -l2));
+          float p = PAD ? __builtin_amdgcn_exp2f(s[qt][kt][r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][kt][r], c2, -l2));
           s[qt][kt][r] = p;
-          dp[qt][kt][r] = p * (dp[qt][kt][r] - dd);
+          dp[qt][kt][r] = PAD ? p * dp[qt][kt][r] : p * (dp[qt][kt][r] - dd);
         }
       }
     // dV^T += dO^T P ; dK^T += Q^T dS ; k index (g, j) <-> query 16(j>>2) + 4g + (j&3)
