@@ -28,7 +28,7 @@ typedef __attribute__((address_space(3))) s4_t lds_s4_t;
 #define CV_BN 128
 #define CV_BK 64
 #ifndef SS_CONV_BIG_MIN_TILES
-#define SS_CONV_BIG_MIN_TILES 128
+#define SS_CONV_BIG_MIN_TILES 64    // uniform-102400 level 3 (105 tiles): pipeline 144 us vs 175 us
 #endif
 #ifndef SS_CONV_DMA_SMALL
 #define SS_CONV_DMA_SMALL false
