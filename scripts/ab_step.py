@@ -27,9 +27,9 @@ def setter(on):
     elif which == "im2col":
         SF.CONV_IM2COL_MAX_SITES = 8192 if on else 0
     elif which == "wgrad_rows":
-        SF.LINEAR_WGRAD_MIN_ROWS = 256 if on else 1024
+        SF.LINEAR_WGRAD_MIN_ROWS = 2048 if on else 1024
     elif which == "im2col_big":
-        SF.CONV_IM2COL_MAX_SITES = 32768 if on else 8192
+        SF.CONV_IM2COL_MAX_SITES = 2048 if on else 8192
     elif which == "coarse15":
         import scenesplat_amd.plan as P
         P.CONV_COARSE_BITS = 17 if on else 15
