@@ -154,8 +154,9 @@ def main():
     impl = {"simt": nv.ATTN_SIMT, "mfma": nv.ATTN_MFMA}.get(args.attn)
     if impl is None:
         impl = nv.ATTN_MFMA if getattr(nv, "HAVE_MFMA_ATTN", False) else nv.ATTN_SIMT
+    from scenesplat_amd.pointcept_api import bench_runtime
+    RUNTIME.update(bench_runtime())          # the configuration tests/test_hip_prod.py pins to the reference
     RUNTIME["attn_impl"] = impl
-    RUNTIME["conv_dtype"] = torch.bfloat16
 
     torch.manual_seed(1234 + rank)
     model = MODELS.build(dict(type="PT-v3m1", **LANG_PTV3)).to(dev).train()

@@ -14,7 +14,8 @@
  *   ss_segment_reduce / ss_segment_bcast      torch_scatter.segment_csr (ptv3:416-421)
  *   ss_gather_rows / ss_scatter_rows / ss_gather_add_rows   feat[idx] row indexing (ptv3:188,216,417,478)
  *   ss_window_attn_fwd / ss_window_attn_bwd   flash_attn.flash_attn_varlen_qkvpacked_func (ptv3:208-214)
- *   ss_lang_head_*                            models/default.py:98-109, losses/misc.py:254-295,355-388
+ *   ss_lang_head_fwd / ss_lang_head_bwd       models/default.py:98-109 (F.normalize), losses/misc.py:254-270
+ *                                             (CosineSimilarity), :274-295 (L2Loss)
  *   ss_knn_query ... ss_bfs_cluster           libs/pointops/src/pointops_api.cpp:15-31,
  *                                             libs/pointops2/src/pointops_api.cpp:17-44,
  *                                             libs/pointgroup_ops/src/bfs_cluster.cpp:140-145
@@ -178,6 +179,22 @@ int ss_bn_act_bwd_apply(const void* dy, int dy_dtype, const void* x, int x_dtype
  * sigmoid(feat text^T) (ties: lowest class), and/or pred_accum[idx ? idx[i] : i][c] += sigmoid(logit). */
 int ss_feat_text_scan(const void* feat_bf16, const void* text_bf16, int64_t n, int dim, int num_classes, float* max_prob,
                       int32_t* argmax, const int32_t* idx, float* pred_accum, ss_stream_t stream);
+
+/* ---- vision-language distillation head (models/default.py:98-109; losses/misc.py:254-295) ----------------
+ * One pass over feat / target (n, C) rows, C % 4 == 0, C <= 2048, dtypes SS_DTYPE_*:
+ *   p = feat / max(|feat|, 1e-12) when normalize (else p = feat); p_out optional (NULL to skip);
+ *   sums (3) f32 = [ sum_valid (1 - cos(p, t)), sum_valid |p - t|^2, #valid ], cos with eps 1e-8 on each norm
+ *   (torch.nn.CosineSimilarity); mask (n) bytes, non-zero = valid.  target NULL: normalisation only (mask, part,
+ *   sums unused).  rowstat (n, 4) f32 is kept for the backward; part = ss_lang_head_blocks(n) * 3 floats of scratch.
+ * Backward: coef (2) f32 DEVICE values dL/dsums[0..1]; dp_extra optional gradient arriving at p from other
+ *   consumers (the contrastive loss); dfeat (n, C). */
+int ss_lang_head_blocks(int64_t n);
+int ss_lang_head_fwd(const void* feat, int feat_dtype, const void* target, int target_dtype, const unsigned char* mask,
+                     int normalize, void* p_out, int p_dtype, float* rowstat, float* part, float* sums, int64_t n,
+                     int channels, ss_stream_t stream);
+int ss_lang_head_bwd(const void* feat, int feat_dtype, const void* target, int target_dtype, const unsigned char* mask,
+                     int normalize, const float* rowstat, const float* coef, const void* dp_extra, int dp_dtype,
+                     void* dfeat, int dfeat_dtype, int64_t n, int channels, ss_stream_t stream);
 
 /* ---- row movement ------------------------------------------------------------------------ */
 int ss_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_dst, int64_t row_bytes, ss_stream_t stream);

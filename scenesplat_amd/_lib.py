@@ -67,6 +67,9 @@ PROTOTYPES = {
     "ss_bn_act_bwd_reduce": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_i, c_p]),
     "ss_bn_act_bwd_apply": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i64, c_i, c_p]),
     "ss_feat_text_scan": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "ss_lang_head_blocks": (c_i, [c_i64]),
+    "ss_lang_head_fwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i64, c_i, c_p]),
+    "ss_lang_head_bwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_i64, c_i, c_p]),
     "ss_gather_rows": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_p]),
     "ss_scatter_rows": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_p]),
     "ss_gather_add_rows": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p]),

@@ -8,6 +8,7 @@ kernels (forward and backward are separate C-ABI entry points).
   subm_conv3d        <- spconv.SubMConv3d on a cached rulebook                         (ptv3:278-284,499-506)
 """
 import os
+import weakref
 
 import torch
 from torch.utils.weak import WeakIdKeyDictionary
@@ -167,14 +168,17 @@ class _SubMConv3dFused(torch.autograd.Function):
         ctx.meta = (feat.dtype, weight.dtype, weight.shape, cin, bias is not None)
         ctx.blocks_fn, ctx.has_dup = blocks_fn, has_dup
         ctx.im2col = (n <= CONV_IM2COL_MAX_SITES) and not has_dup
+        # bf16 out under autocast (the next op is a bf16 GEMM); outside autocast (the evaluator's call form) the output
+        # keeps the input's dtype so that the fp32 Linear that follows sees what the reference's fp32 conv would hand it
+        out_dtype = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
         if ctx.im2col:
             # small level: 26 tiles for 256 CUs and a serial 27-tap loop made the implicit-GEMM kernel latency-bound
             # (70-90 us); neighbour rows side by side + ONE long-K library GEMM takes ~30 us
             cols = nv.subm_im2col(x, nbr)
             out = torch.nn.functional.linear(cols, w.view(cout, -1), bf16_of(bias))
             ctx.save_for_backward(cols, w, nbr, rowperm)
-            return out
-        out = nv.subm_conv_fwd(x, w, None if bias is None else bias.float().contiguous(), nbr, rowperm)
+            return out.to(out_dtype)
+        out = nv.subm_conv_fwd(x, w, None if bias is None else bias.float().contiguous(), nbr, rowperm, out_dtype)
         ctx.save_for_backward(x, w, nbr, rowperm)
         return out
 
@@ -240,10 +244,77 @@ def subm_conv3d(feat, weight, bias, nbr, has_dup=False, compute_dtype=torch.floa
     return _SubMConv3d.apply(feat, weight, bias, nbr, has_dup, compute_dtype)
 
 
+def lang_head_release():
+    """Drop the remembered sums (and with them the autograd graph they hold) once the criteria have run."""
+    _HEAD_CACHE.clear()
+
+
+class _LangHead(torch.autograd.Function):
+    """Fused distillation head (csrc/head.hip): (feat, target, mask) -> (p, sums) with p = normalize(feat) (or feat) and
+    sums = [sum_valid (1 - cos(p, t)), sum_valid |p - t|^2, #valid]; one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, feat, target, mask, normalize, want_p):
+        feat = feat.contiguous()
+        if target is not None:
+            target = target.contiguous()
+            if target.dtype not in (torch.float32, torch.bfloat16):
+                target = target.float()
+        p, sums, rowstat = nv.lang_head_fwd(feat, target, mask, normalize, want_p=want_p)
+        ctx.save_for_backward(feat, target, mask, rowstat)
+        ctx.normalize = normalize
+        ctx.set_materialize_grads(False)
+        return p, sums
+
+    @staticmethod
+    def backward(ctx, dp, dsums):
+        feat, target, mask, rowstat = ctx.saved_tensors
+        if dp is None and (dsums is None or target is None):
+            return None, None, None, None, None
+        coef = None
+        if target is not None:
+            coef = (dsums[:2] if dsums is not None else torch.zeros(2, device=feat.device)).float().contiguous()
+        dp = dp.contiguous() if dp is not None else None
+        return nv.lang_head_bwd(feat, target, mask, ctx.normalize, rowstat, coef, dp), None, None, None, None
+
+
+_HEAD_CACHE = {}
+
+
+def lang_head(feat, target=None, mask=None, normalize=True):
+    """-> (p, sums).  The result is remembered by identity of (p, target, mask): CosineSimilarity / L2Loss called on that
+    p with that target / mask read their sums from it instead of making their own passes (lang_head_sums)."""
+    p, sums = _LangHead.apply(feat, target, mask, normalize, True)
+    if target is not None:
+        _HEAD_CACHE["last"] = (weakref.ref(p), weakref.ref(target), weakref.ref(mask), target._version, mask._version, sums)
+    return p, sums
+
+
+def lang_head_sums(pred, target, mask):
+    """sums for (pred, target, mask): the fused head's when pred came out of lang_head() with the same target / mask
+    (criteria fan-out of LangPretrainer), else one un-normalised pass -- shared by both losses through the same cache."""
+    ent = _HEAD_CACHE.get("last")
+    if ent is not None and ent[0]() is pred and ent[1]() is target and ent[2]() is mask and ent[3] == target._version \
+            and ent[4] == mask._version:
+        return ent[5]
+    _, sums = _LangHead.apply(pred, target, mask, False, False)
+    _HEAD_CACHE["last"] = (weakref.ref(pred), weakref.ref(target), weakref.ref(mask), target._version, mask._version, sums)
+    return sums
+
+
 # ---- bf16 shadows of fp32 parameters ------------------------------------------------------------------
 # torch autocast casts every fp32 weight / bias with its own ~4 us kernel (PT-v3m1: ~250 launches per step).  A model
 # can register its GEMM operands here and refresh ALL shadows with a few multi-tensor copies at the start of forward.
-_SHADOW = WeakIdKeyDictionary()          # keyed by identity (Tensor.__eq__ is elementwise)
+# Every shadow carries the (version counter, storage address) of the parameter it was cast from: bf16_of() hands a
+# shadow out only while that stamp still matches, so a forward that nobody refreshed for (eval without autocast after
+# an optimizer step, load_state_dict, RUNTIME["param_shadows"] = False) gets a fresh cast instead of stale weights,
+# and refresh_shadows() is a no-op while no parameter changed -- a second forward before the backward of the first
+# (LangPretrainer._chunked_forward in training, multi-view losses) does not overwrite tensors an autograd graph saved.
+_SHADOW = WeakIdKeyDictionary()          # parameter -> [bf16 tensor, stamp]; keyed by identity (Tensor.__eq__ is elementwise)
+
+
+def _stamp(p):
+    return (p._version, p.data_ptr())
 
 
 def register_shadows(params):
@@ -252,28 +323,40 @@ def register_shadows(params):
     for p in params:
         if p is None or p.dtype != torch.float32 or not p.is_cuda:
             continue
-        sh = _SHADOW.get(p)
-        if sh is None or sh.shape != p.shape or sh.device != p.device:
-            sh = torch.empty_like(p, dtype=torch.bfloat16)
-            _SHADOW[p] = sh
-        src.append(p); dst.append(sh)
+        ent = _SHADOW.get(p)
+        if ent is None or ent[0].shape != p.shape or ent[0].device != p.device:
+            ent = [torch.empty_like(p, dtype=torch.bfloat16), None]
+            _SHADOW[p] = ent
+        src.append(p); dst.append(ent[0])
     return src, dst
 
 
 @torch.no_grad()
 def refresh_shadows(src, dst):
-    if src:
-        torch._foreach_copy_(dst, src)
+    """Re-cast the parameters whose value changed since their shadow was written (all of them after an optimizer
+    step: one multi-tensor copy; none on a repeated forward)."""
+    todo_s, todo_d = [], []
+    for p, d in zip(src, dst):
+        ent = _SHADOW.get(p)
+        st = _stamp(p)
+        if ent is None or ent[0] is not d or ent[1] != st:
+            todo_s.append(p); todo_d.append(d)
+            if ent is not None and ent[0] is d:
+                ent[1] = st
+    if todo_s:
+        torch._foreach_copy_(todo_d, todo_s)
 
 
 def bf16_of(p):
-    """bf16 copy of an fp32 operand: the registered shadow (refreshed by the owning model) or a fresh cast."""
+    """bf16 copy of an fp32 operand: the registered shadow while it is current, otherwise a fresh cast."""
     if p is None:
         return None
     if p.dtype == torch.bfloat16:
         return p
-    sh = _SHADOW.get(p) if isinstance(p, torch.nn.Parameter) else None
-    return sh if sh is not None else p.to(torch.bfloat16)
+    ent = _SHADOW.get(p) if isinstance(p, torch.nn.Parameter) else None
+    if ent is not None and ent[1] == _stamp(p):
+        return ent[0]
+    return p.to(torch.bfloat16)
 
 
 # ---- deferred weight gradients -----------------------------------------------------------------------------

@@ -470,6 +470,52 @@ def feat_text_scan(feat, text, want_max=True, idx=None, pred_accum=None):
     return mp, am
 
 
+# ---- distillation head ------------------------------------------------------------------------
+def _mask_bytes(mask, n):
+    m = mask if mask.dtype in (torch.bool, torch.uint8) else (mask > 0)
+    m = _req(m.contiguous(), None, "valid_feat_mask", (n,))
+    return m.view(torch.uint8) if m.dtype == torch.bool else m
+
+
+def lang_head_fwd(feat, target, mask, normalize, want_p=True, p_dtype=torch.float32):
+    """-> (p | None, sums (3) f32 | None, rowstat (n,4) f32).  feat / target (n, C) f32 | bf16."""
+    _req(feat, None, "feat")
+    n, C = feat.shape
+    if C % 4 or C > 2048:
+        raise RuntimeError("lang_head: channels must be a multiple of 4 and <= 2048")
+    dev = feat.device
+    p = torch.empty((n, C), dtype=p_dtype, device=dev) if want_p else None
+    rowstat = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    sums = part = m8 = None
+    if target is not None:
+        _req(target, None, "target", (n, C))
+        m8 = _mask_bytes(mask, n)
+        part = torch.empty(lib().ss_lang_head_blocks(n) * 3, dtype=torch.float32, device=dev)
+        sums = torch.empty(3, dtype=torch.float32, device=dev)
+    check(lib().ss_lang_head_fwd(_p(feat), dtype_code(feat), _p(target), dtype_code(target) if target is not None else 0, _p(m8),
+                                 int(bool(normalize)), _p(p), dtype_code(p) if p is not None else 0, _p(rowstat), _p(part), _p(sums),
+                                 n, C, _stream()), "ss_lang_head_fwd")
+    return p, sums, rowstat
+
+
+def lang_head_bwd(feat, target, mask, normalize, rowstat, coef, dp_extra):
+    """-> dfeat (n, C) in feat's dtype.  coef (2) f32 on the device (dL/dsums[0:2]) or None; dp_extra (n, C) or None."""
+    _req(feat, None, "feat"); _req(rowstat, torch.float32, "rowstat")
+    n, C = feat.shape
+    m8 = None
+    if target is not None:
+        _req(target, None, "target", (n, C)); _req(coef, torch.float32, "coef")
+        m8 = _mask_bytes(mask, n)
+    if dp_extra is not None:
+        _req(dp_extra, None, "dp", (n, C))
+    dfeat = torch.empty_like(feat)
+    check(lib().ss_lang_head_bwd(_p(feat), dtype_code(feat), _p(target), dtype_code(target) if target is not None else 0, _p(m8),
+                                 int(bool(normalize)), _p(rowstat), _p(coef), _p(dp_extra),
+                                 dtype_code(dp_extra) if dp_extra is not None else 0, _p(dfeat), dtype_code(dfeat), n, C, _stream()),
+          "ss_lang_head_bwd")
+    return dfeat
+
+
 # ---- rows ------------------------------------------------------------------------------------
 def gather_rows(src, idx, out=None):
     """out[i] = src[idx[i]] (zero row where idx < 0).  src (m, C)."""

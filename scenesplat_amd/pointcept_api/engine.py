@@ -235,7 +235,9 @@ class CheckpointLoader(HookBase):
         weight = tr.cfg.get("weight")
         if not weight or not os.path.isfile(weight):
             return
-        ckpt = torch.load(weight, map_location="cpu", weights_only=False)   # file written by this engine
+        # released / third-party checkpoints come through here: never unpickle arbitrary objects (the engine's own
+        # checkpoint -- state_dict + AdamW + OneCycleLR state + scalars -- loads under weights_only=True)
+        ckpt = torch.load(weight, map_location="cpu", weights_only=True)
         model_sd = tr.model.state_dict()
         wrapped = isinstance(tr.model, nn.parallel.DistributedDataParallel)
         new = OrderedDict()
@@ -339,7 +341,7 @@ class Trainer(TrainerBase):
             self.before_epoch()
             for self.comm_info["iter"], self.comm_info["input_dict"] in self.data_iterator:
                 self.before_step(); self.run_step(); self.after_step()
-                if self.comm_info["iter"] == 2 and self.epoch == self.start_epoch and getattr(self.cfg, "gc_freeze", True):
+                if self.comm_info["iter"] == 2 and self.epoch == self.start_epoch and self.cfg.get("gc_freeze", True):
                     # a step allocates ~10^5 Python objects (autograd nodes, ctypes wrappers); an untimely full
                     # collection over the long-lived model objects stalls the enqueue thread for ~50 ms
                     import gc

@@ -14,36 +14,53 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import functional as SF
 from .. import native as nv
 from .registry import LOSSES, MODELS, build_model
 from .structure import Point
 
 
+def _head_sums(pred, target, valid_feat_mask):
+    """[sum_valid (1 - cos), sum_valid |pred - target|^2, #valid] from the fused head kernel (csrc/head.hip): read once
+    for both losses; reuses LangPretrainer's fused normalise pass when pred came out of it."""
+    if pred.is_cuda and pred.dim() == 2 and pred.shape[1] % 4 == 0 and pred.shape[1] <= 2048 \
+            and pred.dtype in (torch.float32, torch.bfloat16):
+        return SF.lang_head_sums(pred, target, valid_feat_mask)
+    # shapes outside the kernel's contract (odd widths): the same reductions as masked PyTorch-ROCm ops
+    m = (valid_feat_mask > 0).to(pred.dtype)
+    t = target.to(pred.dtype)
+    return torch.stack([((1 - F.cosine_similarity(pred, t, dim=1)) * m).sum(), (((pred - t) ** 2).sum(dim=1) * m).sum(), m.sum()])
+
+
 @LOSSES.register_module()
 class CosineSimilarity(nn.Module):
+    """mean / sum over valid rows of 1 - cos(pred, target) (losses/misc.py:248-270)."""
+
     def __init__(self, reduction="mean", loss_weight=1.0):
         super().__init__()
         self.reduction, self.loss_weight = reduction, loss_weight
 
     def forward(self, pred, target, valid_feat_mask, **kwargs):
-        m = valid_feat_mask.to(pred.dtype)
-        loss = ((1 - F.cosine_similarity(pred, target.to(pred.dtype), dim=1)) * m).sum()
+        sums = _head_sums(pred, target, valid_feat_mask)
+        loss = sums[0]
         if self.reduction == "mean":
-            loss = loss / m.sum().clamp(min=1.0)
+            loss = loss / sums[2].clamp(min=1.0)          # no valid row: the sum (0), as the reference
         return self.loss_weight * loss
 
 
 @LOSSES.register_module()
 class L2Loss(nn.Module):
+    """mean / sum over valid rows of |pred - target|^2 (losses/misc.py:274-295)."""
+
     def __init__(self, reduction="mean", loss_weight=1.0):
         super().__init__()
         self.reduction, self.loss_weight = reduction, loss_weight
 
     def forward(self, pred, target, valid_feat_mask, **kwargs):
-        m = valid_feat_mask.to(pred.dtype)
-        loss = (((pred - target.to(pred.dtype)) ** 2).sum(dim=1) * m).sum()
+        sums = _head_sums(pred, target, valid_feat_mask)
+        loss = sums[1]
         if self.reduction == "mean":
-            loss = loss / m.sum().clamp(min=1.0)
+            loss = loss / sums[2].clamp(min=1.0)
         return self.loss_weight * loss
 
 
@@ -87,8 +104,14 @@ class AggregatedContrastiveLoss(nn.Module):
         valid = (valid_feat_mask > 0) & (segment != -1)
         if rand_keys is None:
             rand_keys = torch.rand(N, device=dev)
+        # labels must lie in [-1, max_classes): the reference gives every distinct label its own class, a clamp would
+        # silently merge the overflow into one.  Checked on the device without a host sync (the failure surfaces as
+        # a device-side assert at the next synchronisation); raise max_classes for larger label spaces.
+        seg64 = segment.long()
+        torch._assert_async(((seg64 >= -1) & (seg64 < Cc)).all(),
+                            "AggregatedContrastiveLoss: segment labels must lie in [-1, max_classes)")
         # sort rows by (class, random key); invalid rows go to a sentinel class at the end
-        cls = torch.where(valid, segment.long().clamp(0, Cc - 1), torch.full_like(segment.long(), Cc))
+        cls = torch.where(valid, seg64.clamp(0, Cc - 1), torch.full_like(seg64, Cc))
         keyi = (rand_keys.double() * (1 << 31)).long().clamp(0, (1 << 31) - 1)
         comp = ((cls << 31) | keyi).unsqueeze(0).contiguous()
         order, _, _ = nv.argsort_i64(comp, 31 + (Cc).bit_length(), want_inverse=False, want_sorted=False)
@@ -154,30 +177,52 @@ class LangPretrainer(nn.Module):
         if chunk_size is not None and chunk_size > 0 and input_dict["coord"].shape[0] > chunk_size:
             return self._chunked_forward(input_dict, chunk_size)
         point_feat = self.backbone(Point(input_dict))
-        point_feat["feat"] = F.normalize(point_feat["feat"].float(), p=2, dim=1)
         if self.training:
-            loss = self.criteria(point_feat["feat"], input_dict["lang_feat"],
-                                 valid_feat_mask=input_dict["valid_feat_mask"],
-                                 segment=input_dict["segment"] if "segment" in input_dict.keys() else None,
-                                 epoch_progress=input_dict["epoch_progress"])
-            return dict(loss=loss)
+            return dict(loss=self._normalize_and_criteria(point_feat["feat"], input_dict, input_dict["epoch_progress"]))
+        point_feat["feat"] = self._normalize(point_feat["feat"])
         return dict(point_feat=point_feat)
 
+    @staticmethod
+    def _fusable(feat):
+        return feat.is_cuda and feat.shape[1] % 4 == 0 and feat.shape[1] <= 2048
+
+    def _normalize(self, feat):
+        """F.normalize(feat, p=2, dim=1) (default.py:96) as one pass of the head kernel."""
+        feat = feat.float()
+        if self._fusable(feat):
+            return SF.lang_head(feat, None, None, True)[0]
+        return F.normalize(feat, p=2, dim=1)
+
+    def _normalize_and_criteria(self, feat, d, epoch_progress):
+        """default.py:96-109: normalise, then the criteria.  The normalisation and the cosine / L2 reductions over
+        (pred, lang_feat) run as ONE pass; the criteria objects find those sums by identity (SF.lang_head_sums)."""
+        feat = feat.float()
+        target, mask = d["lang_feat"], d["valid_feat_mask"]
+        try:
+            pred = SF.lang_head(feat, target, mask, True)[0] if self._fusable(feat) else F.normalize(feat, p=2, dim=1)
+            return self.criteria(pred, target, valid_feat_mask=mask, segment=d["segment"] if "segment" in d.keys() else None,
+                                 epoch_progress=epoch_progress)
+        finally:
+            SF.lang_head_release()
+
     def _chunked_forward(self, input_dict, chunk_size):
-        """Contiguous index-range chunks processed independently (default.py:115-176)."""
+        """Contiguous index-range chunks processed independently (default.py:115-176): every (N, ...) tensor is sliced,
+        offset is rebuilt as [len]; training averages the per-chunk losses, eval concatenates the unit features.
+        As in the reference the per-chunk criteria get epoch_progress=None (the scalar is not an (N, ...) tensor, so it
+        never enters the chunk dict: default.py:137-140,160)."""
         N = input_dict["coord"].shape[0]
         outs = []
         for s in range(0, N, chunk_size):
             e = min(s + chunk_size, N)
             chunk = {k: v[s:e] for k, v in input_dict.items() if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == N}
+            if "condition" in input_dict.keys():
+                chunk["condition"] = input_dict["condition"][0]
             chunk["offset"] = torch.tensor([e - s], device=input_dict["coord"].device)
-            feat = F.normalize(self.backbone(Point(chunk))["feat"].float(), p=2, dim=1)
+            feat = self.backbone(Point(chunk))["feat"]
             if self.training:
-                outs.append(self.criteria(feat, chunk["lang_feat"], valid_feat_mask=chunk["valid_feat_mask"],
-                                          segment=chunk.get("segment", None),
-                                          epoch_progress=input_dict.get("epoch_progress", None)))
+                outs.append(self._normalize_and_criteria(feat, chunk, chunk.get("epoch_progress", None)))
             else:
-                outs.append(feat)
+                outs.append(self._normalize(feat))
         if self.training:
             return dict(loss=torch.stack(outs).mean())
         return dict(point_feat={"feat": torch.cat(outs, dim=0)})

@@ -33,6 +33,12 @@ RUNTIME = dict(attn_impl=nv.ATTN_SIMT, conv_dtype=None,  # conv_dtype None: foll
                param_shadows=os.environ.get("SS_PARAM_SHADOWS", "1") != "0")   # bf16 weight shadows under autocast
 
 
+def bench_runtime():
+    """The execution knobs bench.py times (and tests/test_hip_prod.py holds to the north-star cosine bar): MFMA window
+    attention and bf16 operands for the submanifold conv, under torch bf16 autocast."""
+    return dict(attn_impl=nv.ATTN_MFMA, conv_dtype=torch.bfloat16)
+
+
 class PointModule(nn.Module):
     """Marker base class, as pointcept/models/modules.py:8-14."""
 
@@ -424,7 +430,10 @@ class PointTransformerV3(PointModule):
             offset = point["offset"]  # derived lazily from batch
         # the fused conv consumes bf16: let each block hand the next one a bf16 copy of the residual stream
         self._want_copy = (RUNTIME["conv_dtype"] == torch.bfloat16)
-        if torch.is_autocast_enabled() and RUNTIME.get("param_shadows", True):
+        # bf16 operands are consumed under autocast (Linear) and whenever the conv runs in bf16 -- also without autocast
+        # (the evaluator's no_grad / chunk_size call): refresh in both cases.  Shadows are version-stamped
+        # (SF.bf16_of), so a forward that skips the refresh casts afresh instead of reading stale weights.
+        if (torch.is_autocast_enabled() or self._want_copy) and RUNTIME.get("param_shadows", True):
             self._refresh_shadows()
         plan = point.get("plan", None)
         if plan is None:

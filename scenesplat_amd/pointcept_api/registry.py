@@ -1,87 +1,76 @@
-"""Registry with the reference's build contract: ``REG.build(dict(type=name, **kwargs))``.
+"""Name -> class tables with the reference's build contract: ``REG.build(dict(type=name, **kwargs))``.
 
-Mirrors pointcept/utils/registry.py:9-56,59-316 (mmcv-style) as far as the hot path uses it:
-``register_module(name=None)`` decorator / call form, ``get``, ``build`` with the class-name
-prefixed re-raise of constructor errors (registry.py:52-56)."""
-import inspect
-
-
-def build_from_cfg(cfg, registry, default_args=None):
-    if not isinstance(cfg, dict):
-        raise TypeError(f"cfg must be a dict, but got {type(cfg)}")
-    if "type" not in cfg:
-        if default_args is None or "type" not in default_args:
-            raise KeyError(f'`cfg` or `default_args` must contain the key "type", but got {cfg}\n{default_args}')
-    args = dict(cfg)
-    if default_args is not None:
-        for k, v in default_args.items():
-            args.setdefault(k, v)
-    obj_type = args.pop("type")
-    if isinstance(obj_type, str):
-        obj_cls = registry.get(obj_type)
-        if obj_cls is None:
-            raise KeyError(f"{obj_type} is not in the {registry.name} registry")
-    elif inspect.isclass(obj_type):
-        obj_cls = obj_type
-    else:
-        raise TypeError(f"type must be a str or valid type, but got {type(obj_type)}")
-    try:
-        return obj_cls(**args)
-    except Exception as e:
-        raise type(e)(f"{obj_cls.__name__}: {e}")
+Boundary b1 (pointcept/utils/registry.py:9-56,212 for the contract, not the code): configs name a class by
+``type`` (a registered string or a class object), remaining keys are constructor kwargs, ``default_args`` fill
+keys the config leaves out, and a constructor failure is re-raised as the same exception type with the class name
+in front.  Classes enter a table through ``@REG.register_module()``, ``@REG.register_module("alias")`` or
+``REG.register_module(name=..., module=cls)``.
+"""
 
 
 class Registry:
-    def __init__(self, name, build_func=None):
-        self._name = name
-        self._module_dict = {}
-        self.build_func = build_func or build_from_cfg
+    def __init__(self, name):
+        self.name = name
+        self._table = {}
 
-    def __len__(self):
-        return len(self._module_dict)
-
-    def __contains__(self, key):
-        return self.get(key) is not None
-
-    def __repr__(self):
-        return f"{self.__class__.__name__}(name={self._name}, items={list(self._module_dict)})"
-
-    @property
-    def name(self):
-        return self._name
-
+    # ---- lookup ---------------------------------------------------------------------------------------------
     @property
     def module_dict(self):
-        return self._module_dict
+        return self._table
 
     def get(self, key):
-        return self._module_dict.get(key)
+        return self._table.get(key)
 
-    def build(self, *args, **kwargs):
-        return self.build_func(*args, **kwargs, registry=self)
+    def __contains__(self, key):
+        return key in self._table
 
-    def _register_module(self, module_class, module_name=None, force=False):
-        if not inspect.isclass(module_class):
-            raise TypeError(f"module must be a class, but got {type(module_class)}")
-        names = [module_name] if isinstance(module_name, str) else (module_name or [module_class.__name__])
-        for name in names:
-            if not force and name in self._module_dict:
-                raise KeyError(f"{name} is already registered in {self.name}")
-            self._module_dict[name] = module_class
+    def __len__(self):
+        return len(self._table)
+
+    def __repr__(self):
+        return "Registry(%s: %s)" % (self.name, ", ".join(sorted(self._table)))
+
+    # ---- registration ---------------------------------------------------------------------------------------
+    def _add(self, cls, names, force):
+        if not isinstance(cls, type):
+            raise TypeError("only classes can be registered in %r, got %r" % (self.name, cls))
+        for nm in names:
+            if nm in self._table and not force:
+                raise KeyError("%r already names a class in the %s registry" % (nm, self.name))
+            self._table[nm] = cls
+        return cls
 
     def register_module(self, name=None, force=False, module=None):
-        if isinstance(name, type):  # @REG.register_module without call
-            self._register_module(name)
-            return name
-        if module is not None:
-            self._register_module(module, name, force)
-            return module
+        if isinstance(name, type):                          # bare @REG.register_module
+            return self._add(name, [name.__name__], force)
+        aliases = None if name is None else ([name] if isinstance(name, str) else list(name))
+        if module is not None:                              # call form
+            return self._add(module, aliases or [module.__name__], force)
+        return lambda cls: self._add(cls, aliases or [cls.__name__], force)
 
-        def _register(cls):
-            self._register_module(cls, name, force)
-            return cls
+    # ---- construction ---------------------------------------------------------------------------------------
+    def resolve(self, spec):
+        """A ``type`` entry -> class."""
+        if isinstance(spec, type):
+            return spec
+        if isinstance(spec, str):
+            try:
+                return self._table[spec]
+            except KeyError:
+                raise KeyError("%s is not in the %s registry" % (spec, self.name)) from None
+        raise TypeError("'type' must be a registered name or a class, got %r" % type(spec).__name__)
 
-        return _register
+    def build(self, cfg, default_args=None):
+        if not isinstance(cfg, dict):
+            raise TypeError("config must be a dict, got %r" % type(cfg).__name__)
+        kwargs = {**(default_args or {}), **cfg}            # config keys win over defaults
+        if "type" not in kwargs:
+            raise KeyError("config (or default_args) needs a 'type' key: %r" % (cfg,))
+        cls = self.resolve(kwargs.pop("type"))
+        try:
+            return cls(**kwargs)
+        except Exception as err:                            # plain constructor errors do not say which class failed
+            raise type(err)("%s: %s" % (cls.__name__, err)) from err
 
 
 MODELS = Registry("models")

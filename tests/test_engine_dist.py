@@ -67,7 +67,7 @@ def test_trainer_hook_protocol_and_checkpoint_roundtrip():
         assert calls.count("before_step") == calls.count("after_step") == 10 and calls.count("after_epoch") == 2
         last = os.path.join(tmp, "model", "model_last.pth")
         assert os.path.isfile(last) and os.path.isfile(os.path.join(tmp, "model", "model_best.pth"))
-        ck = torch.load(last, weights_only=False)
+        ck = torch.load(last, weights_only=True)
         assert set(ck) == {"epoch", "state_dict", "optimizer", "scheduler", "scaler", "best_metric_value"} and ck["epoch"] == 2
         # resume: weights with a DDP 'module.' prefix are stripped; epoch restored
         ck["state_dict"] = {"module." + k: v for k, v in ck["state_dict"].items()}

@@ -217,5 +217,5 @@ def test_trainer_runs_lang_pretrainer_on_gpu(tmp_path):
     hist = [h for h in tr.hooks if isinstance(h, engine.InformationWriter)][0].history
     assert len(hist) == 6 and all(np.isfinite(h["loss"]) for h in hist)
     assert hist[-1]["loss"] < hist[0]["loss"]                 # it learns something on repeated data
-    ck = torch.load(os.path.join(str(tmp_path), "model", "model_last.pth"), weights_only=False)
+    ck = torch.load(os.path.join(str(tmp_path), "model", "model_last.pth"), weights_only=True)
     assert ck["epoch"] == 2 and any(k.startswith("backbone.dec.dec0.block0.cpe.0.weight") for k in ck["state_dict"])

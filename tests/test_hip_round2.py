@@ -1,0 +1,287 @@
+"""GPU: fused distillation head, LangPretrainer._chunked_forward, bf16 shadow freshness, BASELINE config 3
+(B = 8 chunks x 102,400 Gaussians with 768-d targets), and the data-parallel path on the real HIP model
+(2 ranks sharing cuda:0 over gloo)."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import losses as olosses
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(in_channels=11, order=("z", "z-trans", "hilbert", "hilbert-trans"), stride=(2, 2),
+            enc_depths=(1, 1, 1), enc_channels=(16, 32, 48), enc_num_head=(1, 2, 3), enc_patch_size=(64, 64, 16),
+            dec_depths=(1, 1), dec_channels=(48, 32), dec_num_head=(1, 2), dec_patch_size=(64, 64))
+CRIT = [dict(type="CosineSimilarity", reduction="mean", loss_weight=1.0),
+        dict(type="L2Loss", reduction="mean", loss_weight=1.0),
+        dict(type="AggregatedContrastiveLoss", temperature=0.2, reduction="mean", loss_weight=0.02, schedule="last_75")]
+
+
+class _Runtime:
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        from scenesplat_amd.pointcept_api import RUNTIME
+        self.old = dict(RUNTIME); RUNTIME.update(self.kw)
+
+    def __exit__(self, *a):
+        from scenesplat_amd.pointcept_api import RUNTIME
+        RUNTIME.clear(); RUNTIME.update(self.old)
+
+
+# ---- fused head ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C", [48, 768])
+def test_fused_head_matches_oracle(C):
+    """normalize + cosine + L2 in one pass (csrc/head.hip) against F.normalize + the oracle's losses, values and the
+    gradient w.r.t. the un-normalised features, with an extra gradient arriving at the unit features."""
+    from scenesplat_amd import functional as SF
+    g = torch.Generator().manual_seed(C)
+    n = 3001
+    feat = torch.randn(n, C, generator=g) * torch.rand(n, 1, generator=g) * 5
+    tgt = F.normalize(torch.randn(n, C, generator=g), dim=1)
+    tgt[5] = 0                                                     # zero-norm target row (eps path of the cosine)
+    mask = torch.rand(n, generator=g) < 0.85
+    wextra = torch.randn(n, C, generator=g) * 1e-3
+    fo = feat.clone().requires_grad_(True)
+    po = F.normalize(fo, p=2, dim=1)
+    lo = 0.7 * olosses.cosine_similarity_loss(po, tgt, mask) + 1.3 * olosses.l2_loss(po, tgt, mask) + (po * wextra).sum()
+    lo.backward()
+    fg = feat.cuda().requires_grad_(True)
+    p, sums = SF.lang_head(fg, tgt.cuda(), mask.cuda(), True)
+    loss = 0.7 * sums[0] / sums[2] + 1.3 * sums[1] / sums[2] + (p * wextra.cuda()).sum()
+    loss.backward()
+    SF.lang_head_release()
+    assert int(sums[2].item()) == int(mask.sum())
+    assert torch.allclose(p.detach().cpu(), po.detach(), atol=2e-7, rtol=1e-6)
+    assert abs(loss.item() - lo.item()) < 3e-6 * abs(lo.item())
+    rel = (fg.grad.cpu() - fo.grad).norm() / fo.grad.norm()
+    print("fused head C=%d: loss %.6f vs %.6f, grad rel err %.2e" % (C, loss.item(), lo.item(), rel))
+    assert rel < 1e-5
+    # bf16 features in (what a bf16 backbone would hand over): same math on the rounded values
+    fb = feat.to(torch.bfloat16).cuda().requires_grad_(True)
+    pb, sb = SF.lang_head(fb, tgt.cuda(), mask.cuda(), True)
+    (sb[0] / sb[2]).backward()
+    SF.lang_head_release()
+    fo2 = feat.to(torch.bfloat16).float().requires_grad_(True)
+    l2 = olosses.cosine_similarity_loss(F.normalize(fo2, dim=1), tgt, mask)
+    l2.backward()
+    assert abs((sb[0] / sb[2]).item() - l2.item()) < 1e-5
+    assert (fb.grad.float().cpu() - fo2.grad).norm() / fo2.grad.norm() < 6e-3          # bf16 gradient storage
+
+
+def test_criteria_share_one_head_pass_and_match_reference(golden_dir):
+    """LangPretrainer's criteria fan-out: CosineSimilarity and L2Loss find the fused pass by identity (no second read),
+    and the standalone call form (pred already unit rows) reproduces the reference's golden losses."""
+    from scenesplat_amd import functional as SF
+    from scenesplat_amd.pointcept_api import build_criteria
+    fx = np.load(os.path.join(golden_dir, "losses.npz"))
+    pred0, tgt = torch.from_numpy(fx["pred"]).cuda(), torch.from_numpy(fx["tgt"]).cuda()
+    mask, seg = torch.from_numpy(fx["mask"]).cuda(), torch.from_numpy(fx["seg"]).cuda()
+    crit = build_criteria(CRIT)
+    calls = []
+    orig = SF._LangHead.apply
+    SF._LangHead.apply = staticmethod(lambda *a: (calls.append(a[3]), orig(*a))[1])
+    try:
+        raw = (pred0 * 3.0).requires_grad_(True)                       # un-normalised features with the same directions
+        p, _ = SF.lang_head(raw, tgt, mask, True)
+        loss = crit(p, tgt, valid_feat_mask=mask, segment=seg, epoch_progress=0.1)
+        SF.lang_head_release()
+        assert calls == [True]                                         # one fused pass; neither loss made its own
+        loss.backward()
+        assert abs(loss.item() - float(fx["loss_ep0.1"])) < 3e-6 * abs(float(fx["loss_ep0.1"]))
+        calls.clear()
+        pr = pred0.clone().requires_grad_(True)
+        loss2 = crit(pr, tgt, valid_feat_mask=mask, segment=seg, epoch_progress=0.1)
+        assert calls == [False]                                        # standalone: ONE shared un-normalised pass
+        loss2.backward()
+        assert abs(loss2.item() - float(fx["loss_ep0.1"])) < 2e-6 * abs(float(fx["loss_ep0.1"])) + 1e-6
+        assert torch.allclose(pr.grad.cpu(), torch.from_numpy(fx["dpred_ep0.1"]), atol=1e-7, rtol=1e-4)
+    finally:
+        SF._LangHead.apply = orig
+        SF.lang_head_release()
+
+
+# ---- LangPretrainer._chunked_forward ----------------------------------------------------------------------------
+def _tiny_lang(drop_path=0.0):
+    from scenesplat_amd.pointcept_api import MODELS
+    torch.manual_seed(5)
+    return MODELS.build(dict(type="LangPretrainer", backbone=dict(type="PT-v3m1", **TINY, drop_path=drop_path, shuffle_orders=False),
+                             criteria=CRIT)).cuda()
+
+
+def _tiny_input(n_side=40, seed=0):
+    from scenesplat_amd.synthetic import room_chunk
+    d = {k: v.cuda() for k, v in room_chunk(n_side=n_side, seed=seed, lang_dim=48, num_classes=4).items()}
+    d["epoch_progress"] = 0.6
+    return d
+
+
+def test_chunked_forward_eval_equals_per_chunk_forwards():
+    """models/default.py:115-176: chunk_size < N in eval -> the concatenation of independent per-chunk forwards
+    (each chunk re-serialised on its own), unit rows."""
+    model = _tiny_lang().eval()
+    d = _tiny_input()
+    n = d["coord"].shape[0]
+    cs = 1000
+    assert n > 2 * cs
+    with torch.no_grad():
+        torch.manual_seed(3)
+        full = model(d, chunk_size=cs)["point_feat"]["feat"]
+        torch.manual_seed(3)
+        parts = []
+        for s in range(0, n, cs):
+            e = min(s + cs, n)
+            sub = {k: v[s:e] for k, v in d.items() if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n}
+            sub["offset"] = torch.tensor([e - s], device="cuda"); sub["epoch_progress"] = 0.6
+            parts.append(model(sub)["point_feat"]["feat"])
+        whole = model(d, chunk_size=600000)["point_feat"]["feat"]        # evaluator.py:762 call form, N < chunk_size
+    assert full.shape == (n, 48) and torch.equal(full, torch.cat(parts))
+    assert torch.allclose(full.norm(dim=1), torch.ones(n, device="cuda"), atol=1e-5)
+    assert not torch.allclose(full, whole, atol=1e-3)                    # chunking changes the context, as in the reference
+
+
+def test_chunked_forward_training_bf16_runs_several_forwards_before_one_backward():
+    """Training with chunk_size < N under bf16 autocast: one backbone forward per chunk, ONE backward over the mean of
+    the chunk losses.  The bf16 weight shadows must not be overwritten between those forwards (the autograd graph of
+    the first chunk saved them), and the loss must equal the mean of the per-chunk losses."""
+    from scenesplat_amd import native as nv
+    model = _tiny_lang().train()
+    d = _tiny_input()
+    n = d["coord"].shape[0]
+    cs = 1200
+    with _Runtime(conv_dtype=torch.bfloat16, attn_impl=nv.ATTN_MFMA):
+        torch.manual_seed(4)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(d, chunk_size=cs)
+        out["loss"].backward()
+        g1 = {k: p.grad.clone() for k, p in model.named_parameters()}
+        assert all(torch.isfinite(g).all() for g in g1.values())
+        model.zero_grad()
+        torch.manual_seed(4)
+        losses = []
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            for s in range(0, n, cs):
+                e = min(s + cs, n)
+                sub = {k: v[s:e] for k, v in d.items() if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == n}
+                sub["offset"] = torch.tensor([e - s], device="cuda"); sub["epoch_progress"] = None
+                losses.append(model(sub)["loss"])
+        ref = torch.stack(losses).mean()
+    assert abs(out["loss"].item() - ref.item()) < 1e-5 * abs(ref.item()) + 1e-6
+
+
+def test_bf16_shadows_follow_the_parameters():
+    """autocast train step -> optimizer.step -> eval forward WITHOUT autocast (the evaluator's call form) with the conv
+    in bf16: must use the updated conv weights (equal to a fresh model holding the same state dict), also with the
+    refresh switched off."""
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.pointcept_api import MODELS
+    d = _tiny_input(32, 1)
+    inp = dict(feat=d["feat"], grid_coord=d["grid_coord"], offset=d["offset"])
+    for shadows in (True, False):
+        with _Runtime(conv_dtype=torch.bfloat16, attn_impl=nv.ATTN_SIMT, param_shadows=shadows):
+            torch.manual_seed(0)
+            model = MODELS.build(dict(type="PT-v3m1", **TINY, drop_path=0.0, shuffle_orders=False)).cuda().train()
+            opt = torch.optim.SGD(model.parameters(), lr=0.5)
+            for _ in range(2):
+                torch.manual_seed(1)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = model(dict(inp)).feat
+                opt.zero_grad(); y.float().square().mean().backward(); opt.step()
+            model.eval()
+            fresh = MODELS.build(dict(type="PT-v3m1", **TINY, drop_path=0.0, shuffle_orders=False)).cuda().eval()
+            fresh.load_state_dict(model.state_dict())
+            with torch.no_grad():
+                torch.manual_seed(2); a = model(dict(inp)).feat
+                torch.manual_seed(2); b = fresh(dict(inp)).feat
+            assert torch.equal(a, b), (shadows, (a - b).abs().max())
+
+
+# ---- BASELINE config 3 -------------------------------------------------------------------------------------------
+def test_config3_lang_pretrainer_b8_x_102400_one_step():
+    """ScanNet vision-language pretrain shape: LangPretrainer (PT-v3m1 lang config + 3 criteria), batch = 8 chunks of
+    102,400 Gaussians with 768-d targets, one bf16 training step on one GPU: finite loss, every parameter gets a
+    finite gradient, peak memory inside one MI355X's 288 GB."""
+    from scenesplat_amd.pointcept_api import MODELS, bench_runtime
+    from scenesplat_amd.synthetic import LANG_PTV3, room_chunk
+    torch.cuda.reset_peak_memory_stats()
+    with _Runtime(**bench_runtime()):
+        torch.manual_seed(0)
+        model = MODELS.build(dict(type="LangPretrainer", backbone=dict(type="PT-v3m1", **LANG_PTV3), criteria=CRIT)).cuda().train()
+        data = {k: v.cuda() for k, v in room_chunk(n_side=256, seed=0, lang_dim=768, batch=8).items()}
+        data["epoch_progress"] = 0.5
+        assert data["feat"].shape[0] == 8 * 102400 and data["lang_feat"].shape == (819200, 768)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = model(data)["loss"]
+        loss.backward()
+        torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() / 2**30
+    print("config 3: loss %.4f, peak memory %.1f GiB" % (loss.item(), peak))
+    assert torch.isfinite(loss) and 0.5 < loss.item() < 4.0
+    assert peak < 268.0                                             # 288 GB = 268 GiB
+    bad = [k for k, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    assert not bad, bad[:5]
+
+
+# ---- data parallel on the real model ---------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.pointcept_api import MODELS, RUNTIME, engine
+    from scenesplat_amd.synthetic import room_chunk
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    RUNTIME.update(conv_dtype=torch.bfloat16, attn_impl=nv.ATTN_MFMA)
+    torch.manual_seed(0)
+    model = MODELS.build(dict(type="LangPretrainer", backbone=dict(type="PT-v3m1", **TINY, drop_path=0.1, shuffle_orders=True),
+                              criteria=CRIT)).cuda()
+    ddp = engine.create_ddp_model(model, broadcast_buffers=False)
+    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    opt = torch.optim.AdamW(ddp.parameters(), lr=1e-3)
+    ddp.train()
+    losses = []
+    for step in range(2):
+        d = {k: v.cuda() for k, v in room_chunk(n_side=32, seed=10 * rank + step, lang_dim=48, num_classes=4).items()}
+        d["epoch_progress"] = 0.6
+        torch.manual_seed(100 + rank + step)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = ddp(d)["loss"]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    torch.cuda.synchronize()
+    sd = {k: v.detach().float().cpu().numpy().copy() for k, v in model.state_dict().items() if v.is_floating_point() and "running_" not in k}
+    q.put((rank, sd, losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ddp_two_ranks_on_the_hip_model_end_with_identical_weights():
+    """engines/defaults.py:13-34 on the real HIP LangPretrainer: 2 processes share cuda:0 (gloo; RCCL needs one GPU per
+    rank), different data per rank, 2 optimizer steps.  DDP's bucket hooks must see the gradients of the custom
+    autograd Functions (incl. the fp32 weight-gradient arena): both ranks end with IDENTICAL weights."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=500) for _ in range(world)], key=lambda r: r[0])
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert res[0][2] != res[1][2]                                   # different shards -> different losses
+    for k in res[0][1]:
+        assert np.array_equal(res[0][1][k], res[1][1][k]), k
+    assert all(np.isfinite(v).all() for v in res[0][1].values())

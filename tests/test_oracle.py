@@ -199,3 +199,66 @@ def test_pool_partition_sizes():
     assert len(head) == len(np.unique(code[0] >> 3)) == len(idx_ptr) - 1
     for k in range(4):
         assert np.array_equal(ncode[k][cluster], code[k] >> 3)
+
+
+# ---- production widths (tests/golden/make_golden_prod.py) -----------------------------------------------------
+def _prod():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("prod_inputs", os.path.join(os.path.dirname(__file__), "golden", "prod_inputs.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def test_prod_attention_matches_reference(golden_dir):
+    """The oracle's SerializedAttention at the dec0 width (C=768, 16 heads of 48, K=1024, padded tail window)
+    against the reference module's outputs and gradients."""
+    mp = _prod()
+    fx = load(golden_dir, "attention_prod.npz")
+    gc, x, cot, sd = mp.att_inputs()
+    n, K, H = mp.ATT["n"], mp.ATT["K"], mp.ATT["H"]
+    for v in sd.values():
+        v.requires_grad_(True)
+    x.requires_grad_(True)
+    lv = optv3.build_levels(gc.numpy(), np.array([n]), mp.ORD, ())[0]
+    y = optv3.attention(x, sd, "", lv, mp.ATT["order_index"], H, K)
+    (y * cot).sum().backward()
+    rows = torch.from_numpy(fx["rows"])
+    ref = torch.from_numpy(fx["y_rows"]).float()
+    assert (1 - F.cosine_similarity(y.detach()[rows], ref, dim=1)).max() < 1e-6
+    assert _rel(mp.proj(y), fx["y_proj"]) < 1e-5 and _rel(mp.proj(x.grad), fx["dx_proj"]) < 1e-5
+    assert _rel(x.grad[rows], torch.from_numpy(fx["dx_rows"]).float()) < 1e-3          # fp16 storage
+    for k, v in sd.items():
+        assert _rel(mp.proj(v.grad), fx["grad_proj_" + k]) < 1e-4, k
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_prod_lang_ptv3_matches_reference(golden_dir, mode):
+    """The oracle's full lang-pretrain PT-v3m1 (91.71 M parameters) on the 6,400-Gaussian room against the reference
+    model: per-Gaussian cosine on the stored rows, projections of every row, input and parameter gradients."""
+    mp = _prod()
+    fx = load(golden_dir, "ptv3_lang_prod.npz")
+    cfg = dict(optv3.DEFAULT_CFG)
+    sd = optv3.init_state_dict(cfg, seed=5)
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    gc, feat, cot = mp.lang_inputs()
+    feat.requires_grad_(True)
+    torch.manual_seed(mp.POOL_SEED)
+    perms = [np.arange(4)] + [torch.randperm(4).numpy() for _ in cfg["stride"]]
+    y = optv3.forward(sd, cfg, feat, gc.numpy(), np.array([len(gc)]), bn_training=(mode == "train"), perms=perms)
+    (y * cot).sum().backward()
+    rows = torch.from_numpy(fx["rows"])
+    cosd = 1 - F.cosine_similarity(y.detach()[rows], torch.from_numpy(fx[f"{mode}_y_rows"]).float(), dim=1)
+    print("oracle vs reference, lang model (%s): max cosine distance %.2e" % (mode, cosd.max()))
+    assert cosd.max() < 1e-6
+    assert _rel(mp.proj(y), fx[f"{mode}_y_proj"]) < 1e-4
+    assert _rel(feat.grad, fx[f"{mode}_dfeat"]) < 2e-3
+    for k in mp.GRAD_KEYS:
+        assert _rel(mp.proj(sd[k].grad), fx[f"{mode}_grad_proj_{k}"]) < 3e-3, k
