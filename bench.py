@@ -22,8 +22,6 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
-MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak
 
 
 def parse():
@@ -39,74 +37,88 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--cpu-n-side", type=int, default=128, help="room side of the CPU-baseline sample (128 -> 25,600 Gaussians, ~10-20 s on 16 cores)")
+    ap.add_argument("--cpu-n-side", type=int, default=256, help="room side of the CPU-baseline chunk (256 -> the metric's 102,400 Gaussians, about a minute on 16 cores)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline traffic = null)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config-3 and fp32-conv secondary lines")
     return ap.parse_args()
 
 
-def event_time_ms(fn, iters, warmup=2):
-    for _ in range(warmup):
-        fn()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
-        fn()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / iters
+def _probes_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("roofline_probes", os.path.join(ROOT, "scripts", "roofline_probes.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
 
 
-def roofline_probes(model, data, impl):
-    """Isolated launches of the kernels the north star prices, at the dec0 shapes of the workload, timed with HIP
-    events on the launch stream: the dominant kernel (submanifold conv forward / dgrad on the LDS-DMA pipeline,
-    MFMA-bound), the window attention forward (MFMA / VALU-bound) and the row gather (HBM-bound)."""
-    from scenesplat_amd import native as nv
-    from scenesplat_amd.plan import build_plan
-    plan = build_plan(data["grid_coord"], data["offset"], model.order, model.stride)
-    lv = plan.levels[0]
-    C, H, K = 768, 16, 1024
-    g = torch.Generator(device="cuda").manual_seed(0)
-    pmc = {}
+def pmc_traffic(log, timeout_s=240):
+    """HBM-side bytes per launch of the probe kernels, MEASURED IN THIS RUN: two rocprofv3 child passes (FETCH_SIZE, then
+    WRITE_SIZE: the TCC block cannot hold both, MI355X_MICROARCH.md "rocprofv3 PMC slots") over scripts/roofline_probes.py,
+    counters only (--kernel-trace, no other trace domain).  gfx950 correction: FETCH_SIZE counts 64 B per 128-B request
+    on wide coalesced reads -> doubled; WRITE_SIZE exact; both in KB.  Returns {kernel substring: bytes} or {} (then the
+    bench line carries traffic = null rather than a stale number)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        log("pmc: rocprofv3 not on PATH, traffic = null")
+        return {}
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="ss_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
     try:
-        # HBM-side bytes per launch at this shape, from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE, gfx950 correction applied; scripts/gpu_pmc.sh)
-        if lv.n == 102400:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-    except Exception:
-        pass
-    # --- dominant kernel: k_gemm8<true> (CPE conv of the dec0 blocks: 4 launches per step fwd + dgrad)
-    nbr, perm = lv.neighbors(3), lv.conv_rowperm()
-    x = torch.randn(lv.n, C, device="cuda", generator=g).to(torch.bfloat16)
-    w = (torch.randn(C, 27, C, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
-    pairs = int((nbr >= 0).sum().item())
-    ms_c = event_time_ms(lambda: nv.subm_conv_fwd(x, w, None, nbr, perm), 5)
-    flops_c = 2.0 * pairs * C * C
-    conv = dict(bound="mfma", kernel="k_gemm8<true> subm conv fwd (dec0: n=%d, C=%d, 27 taps, %.2f pairs/site)" % (lv.n, C, pairs / lv.n),
-                achieved=flops_c / (ms_c * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
-                frac=flops_c / (ms_c * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
-                traffic=pmc.get("k_gemm8<true>@dec0", {}).get("traffic_bytes_corrected"), traffic_unit="bytes/launch beyond L2 (PMC)",
-                algorithmic_flops=flops_c, algorithmic_bytes=lv.n * C * 2 * 2 + 27 * C * C * 2, ms=ms_c)
-    # --- window attention forward
-    win = lv.window(0, K)
-    qkv = torch.randn(lv.n, 3 * C, device="cuda", generator=g).to(torch.bfloat16)
-    ms = event_time_ms(lambda: nv.window_attn_fwd(qkv, win, H, (C // H) ** -0.5, impl), 5)
-    flops = sum(4.0 * L * L * (C // H) for L in [K] * win.num_windows) * H
-    attn = dict(bound="mfma", kernel="k_attn_fwd_mfma<48> (dec0: %d windows x %d heads, K=%d, d=%d)" % (win.num_windows, H, K, C // H),
-                achieved=flops / (ms * 1e-3) / 1e12, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
-                frac=flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
-                traffic=pmc.get("k_attn_fwd_mfma<48>@dec0", {}).get("traffic_bytes_corrected"), traffic_unit="bytes/launch (PMC)",
-                algorithmic_flops=flops, ms=ms)
-    idx = lv.order_row(0)
-    out = torch.empty_like(x)
-    ms2 = event_time_ms(lambda: nv.gather_rows(x, idx, out=out), 20)
-    nbytes = lv.n * (2 * C * 2 + 4)
-    hbm = dict(bound="hbm", kernel="gather_rows(%d x %d bf16)" % (lv.n, C), achieved=nbytes / (ms2 * 1e-3) / 1e9,
-               peak=HBM_PEAK_GBS, unit="GB/s", frac=nbytes / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, ms=ms2)
-    return conv, attn, hbm
+        for counter, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.join(ROOT, "scripts", "roofline_probes.py")]
+            t0 = time.time()
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            log("pmc pass %s: rc %d, %.0f s" % (counter, r.returncode, time.time() - t0))
+            if r.returncode != 0:
+                return {}
+            acc = {}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter:
+                        acc.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            for k, v in acc.items():
+                # per launch: the probe program launches each kernel three times at one shape; max (not mean) so that a
+                # smaller launch of the same kernel during the probes' set-up (plan building) cannot dilute it
+                out.setdefault(k, 0.0)
+                out[k] += mult * 1024.0 * max(v)
+    except Exception as e:   # noqa: BLE001  (profiling is best effort; the timed numbers do not depend on it)
+        log("pmc: %s: %s" % (type(e).__name__, e))
+        return {}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
-def cpu_baseline(n_side):
-    """Oracle (pure-PyTorch fp32 CPU restatement of the reference path) fwd+bwd on a bounded
-    sample of the same workload: the full lang-pretrain PT-v3m1 on a room of n_side."""
+def roofline_lines(log, want_pmc):
+    """roofline objects of the bench line: every probe timed with HIP events in THIS process, PMC traffic from child passes."""
+    rp = _probes_module()
+    probes = rp.build()
+    traffic = pmc_traffic(log) if want_pmc else {}
+    res = {}
+    for p in probes:
+        ms = rp.time_probe(p, iters=10 if p["bound"] == "hbm" else 5)
+        tr = [v for k, v in traffic.items() if p["kernel"] in k]
+        res[p["name"]] = rp.roofline_entry(p, ms, sum(tr) if tr else None)
+        log("probe %-10s %.3f ms  %.0f %s (%.1f %% of peak)%s" % (p["name"], ms, res[p["name"]]["achieved"], res[p["name"]]["unit"],
+                                                                  100 * res[p["name"]]["frac"],
+                                                                  "  traffic %.0f MB" % (sum(tr) / 1e6) if tr else ""))
+    return res
+
+
+def cpu_baseline(n_side, log):
+    """Oracle (pure-PyTorch fp32 CPU restatement of the reference path, kind "port") fwd+bwd of the full lang-pretrain
+    PT-v3m1 on one room chunk of the metric's size (n_side 256 -> 102,400 Gaussians; about a minute on 16 cores).  A
+    heartbeat thread prints a progress line every 20 s: the GPU box's silence monitor kills a command that writes nothing
+    for 7 minutes, and an earlier, slower oracle ran the full chunk in silence (gpurun_out/run3.log, run10.log: rc 137)."""
+    import threading
     from oracle import ptv3 as optv3
     from scenesplat_amd.synthetic import LANG_PTV3, room_chunk
     # the GPU box gives one GPU a 16-core share; os.cpu_count() reports the whole host and oversubscribes
@@ -120,11 +132,95 @@ def cpu_baseline(n_side):
     n = len(data["feat"])
     cot = torch.randn(n, cfg["dec_channels"][0], generator=torch.Generator().manual_seed(1))
     t0 = time.time()
-    y = optv3.forward(sd, cfg, data["feat"], data["grid_coord"].numpy(), data["offset"].numpy(), bn_training=True)
-    (y * cot).sum().backward()
+    stop = threading.Event()
+    stage = ["forward"]
+
+    def beat():
+        while not stop.wait(20.0):
+            log("cpu baseline: %s, %.0f s elapsed (%d Gaussians, %d threads)" % (stage[0], time.time() - t0, n, torch.get_num_threads()))
+
+    th = threading.Thread(target=beat, daemon=True)
+    th.start()
+    try:
+        y = optv3.forward(sd, cfg, data["feat"], data["grid_coord"].numpy(), data["offset"].numpy(), bn_training=True)
+        tf = time.time() - t0
+        stage[0] = "backward (forward took %.0f s)" % tf
+        (y * cot).sum().backward()
+    finally:
+        stop.set()
     dt = time.time() - t0
     return dict(value=n / dt, unit="Gaussians/s", cores=torch.get_num_threads(), kind="port",
-                sample="1 fwd+bwd of the full lang-pretrain PT-v3m1 (fp32, oracle) on a %d-Gaussian room chunk, %.1f s" % (n, dt))
+                sample="1 fwd+bwd of the full lang-pretrain PT-v3m1 (fp32, oracle) on one %d-Gaussian room chunk, %.1f s" % (n, dt))
+
+
+def secondary_lines(log, steps=3):
+    """Secondary measurements next to the headline (never `value`): BASELINE config 3 -- LangPretrainer (PT-v3m1 + fused
+    normalise/cosine/L2 head + contrastive loss) at B = 8 chunks x 102,400 Gaussians with 768-d targets -- and the headline
+    workload with the conv in the REFERENCE's precision (fp32 operands, modules.py:64-75) instead of bf16."""
+    import gc
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.pointcept_api import MODELS, RUNTIME, bench_runtime
+    from scenesplat_amd.synthetic import LANG_PTV3, room_chunk
+    out = {}
+    old = dict(RUNTIME)
+    side = torch.cuda.Stream()
+
+    def run(model, backbone, data, loss_mode, tag, n_steps):
+        st = {"plan": backbone.prepare_plan(data, stream=side)}
+        cot = None if loss_mode else torch.randn(data["feat"].shape[0], 768, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            plan, st["plan"] = st["plan"], None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                o = model(dict(data, plan=plan))
+            if loss_mode:
+                o["loss"].backward()
+            else:
+                torch.autograd.backward(o.feat, grad_tensors=cot.to(o.feat.dtype))
+            st["plan"] = backbone.prepare_plan(data, stream=side)
+
+        for i in range(2):
+            t_ = time.perf_counter(); step(); torch.cuda.synchronize()
+            log("%s warm-up %d: %.1f ms" % (tag, i, (time.perf_counter() - t_) * 1e3))
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n_steps
+
+    try:
+        RUNTIME.update(bench_runtime())
+        crit = [dict(type="CosineSimilarity", reduction="mean", loss_weight=1.0), dict(type="L2Loss", reduction="mean", loss_weight=1.0),
+                dict(type="AggregatedContrastiveLoss", temperature=0.2, reduction="mean", loss_weight=0.02, schedule="last_75")]
+        torch.manual_seed(1)
+        model = MODELS.build(dict(type="LangPretrainer", backbone=dict(type="PT-v3m1", **LANG_PTV3), criteria=crit)).cuda().train()
+        data = {k: v.cuda() for k, v in room_chunk(256, 0, lang_dim=768, batch=8).items()}
+        data["epoch_progress"] = 0.5
+        n = data["feat"].shape[0]
+        torch.cuda.reset_peak_memory_stats()
+        dt = run(model, model.backbone, data, True, "config 3 (B=8 LangPretrainer)", steps)
+        out["config3_lang_pretrainer_b8"] = dict(metric="Gaussians/s LangPretrainer fwd+bwd incl. distillation head, 8 x 102,400-Gaussian chunks, 768-d targets, 1 GPU",
+                                                 value=n / dt, unit="Gaussians/s", ms_per_step=dt * 1e3, steps=steps,
+                                                 peak_mem_GiB=torch.cuda.max_memory_allocated() / 2**30, dtype="bf16")
+        del model, data
+        gc.collect(); torch.cuda.empty_cache()
+        RUNTIME["conv_dtype"] = None          # the reference's conv precision: fp32 operands (per-tap gather + fp32 GEMM)
+        torch.manual_seed(1)
+        model = MODELS.build(dict(type="PT-v3m1", **LANG_PTV3)).cuda().train()
+        data = {k: v.cuda() for k, v in room_chunk(256, 0, lang_dim=0).items()}
+        dt = run(model, model, data, False, "conv fp32 (reference semantics)", steps)
+        out["conv_fp32_reference_precision"] = dict(metric="Gaussians/s encoder fwd+bwd, 102k-pt chunk, submanifold conv with fp32 operands (reference semantics), other GEMMs bf16",
+                                                    value=data["feat"].shape[0] / dt, unit="Gaussians/s", ms_per_step=dt * 1e3, steps=steps,
+                                                    dtype="bf16 autocast + fp32 conv")
+        del model, data
+        gc.collect(); torch.cuda.empty_cache()
+    except Exception as e:   # noqa: BLE001  (secondary lines must never take the headline down)
+        log("secondary: %s: %s" % (type(e).__name__, e))
+        out["error"] = "%s: %s" % (type(e).__name__, e)
+    finally:
+        RUNTIME.clear(); RUNTIME.update(old)
+    return out
 
 
 def main():
@@ -244,13 +340,23 @@ def main():
         }
         log("timed %d steps: %.1f ms/step" % (args.steps, dt / args.steps * 1e3))
         if world == 1:
-            conv, attn, hbm = roofline_probes(model, data, impl)
-            log("roofline probes done")
-            res["roofline"] = conv
-            res["roofline_attn"] = attn
-            res["roofline_hbm"] = hbm
+            import gc
+            state.clear()
+            net = model = None                                 # (cells of step(): releases the model and its plan)
+            gc.collect(); torch.cuda.empty_cache()
+            rl = roofline_lines(log, not args.no_pmc)
+            res["roofline"] = rl["conv_fwd"]                  # the dominant kernel of the step
+            res["roofline_conv_wgrad"] = rl["conv_wgrad"]
+            res["roofline_attn"] = rl["attn_fwd"]             # the kernel the north star names
+            res["roofline_attn_bwd"] = rl["attn_bwd"]
+            res["roofline_hbm"] = rl["gather_hbm"]            # gather/scatter family on a working set far beyond the Infinity Cache
+            res["roofline_scan"] = rl["scan"]
+            del rl
+            gc.collect(); torch.cuda.empty_cache()
+            if not args.no_secondary:
+                res["secondary"] = secondary_lines(log)
             if not args.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline(args.cpu_n_side)
+                res["cpu_baseline"] = cpu_baseline(args.cpu_n_side, log)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -16,3 +16,6 @@ int ss_attn_fwd_mfma(const void* qkv, const int32_t* gidx, const int32_t* sidx, 
 int ss_attn_bwd_mfma(const void* qkv, const void* dout, const void* out, const float* lse, float* delta, const int32_t* gidx,
                      const int32_t* sidx, const int32_t* win_start, int W, int max_window, void* dqkv, void* extra,
                      int C, int H, float scale, hipStream_t st);
+// 32x32x16 re-tiling of the forward (attention_mfma32.hip); same contract as ss_attn_fwd_mfma
+int ss_attn_fwd_mfma32(const void* qkv, const int32_t* gidx, const int32_t* sidx, const int32_t* win_start, int W,
+                       int max_window, void* out, float* lse, int C, int H, float scale, hipStream_t st);

@@ -15,6 +15,7 @@
 // LDS images: "row" images ([row][DP] bf16, XOR-swizzled 16-B chunks, conflict-free
 // ds_read_b128) and "tr" images ([row][D] plain, for the transposed reads).
 #include "attention_internal.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
 typedef __attribute__((ext_vector_type(4))) short s4_t;
@@ -764,6 +765,9 @@ int ss_attn_fwd_mfma(const void* qkv, const int32_t* gidx, const int32_t* sidx, 
                      int max_window, void* out, float* lse, int C, int H, float scale, hipStream_t st) {
   const int D = C / H;
   if ((C & 7) || max_window <= 0 || max_window > FA_IDX_CAP) return SS_ERR_ARG;
+  // SS_ATTN_FWD32=0 (diagnostic A/B switch, read once) keeps the 16x16x32 forward
+  static const int use32 = [] { const char* e = getenv("SS_ATTN_FWD32"); return e ? atoi(e) : 1; }();
+  if (use32) return ss_attn_fwd_mfma32(qkv, gidx, sidx, win_start, W, max_window, out, lse, C, H, scale, st);
   const int qchunks = (max_window + FA_BQ - 1) / FA_BQ;
   dim3 g((unsigned)(W * H * qchunks)), b(FA_THREADS);
   const unsigned short* q = (const unsigned short*)qkv; unsigned short* o = (unsigned short*)out;

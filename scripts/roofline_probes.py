@@ -1,0 +1,126 @@
+#!/usr/bin/env python
+"""Isolated launches of the kernels bench.py prices against a roofline, at the shapes of the metric's workload.
+
+Two uses:
+  * imported by bench.py: `build(...)` returns the probes, `time_probe` times one with HIP events on the launch stream;
+  * run as a program under `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace` (bench.py starts those passes as CHILD
+    processes after its timed region): launches every probe a few times so the counter CSV holds per-launch bytes of
+    exactly the kernels, shapes and build that were just timed.
+
+Algorithmic work per launch (DESIGN.md section 4 / SURVEY 8d):
+  conv_fwd / conv_wgrad  dec0 submanifold conv, n = 102,400 sites, C = 768: 2 * pairs * C^2 FLOP; bytes 2 n C 2 + 27 C^2 2
+  attn_fwd / attn_bwd    dec0 window attention: 100 windows x 16 heads, K = 1024, d = 48: 4 K^2 d per (window, head) FLOP
+                         forward, 2.5 x backward (5 products, recompute not counted); bytes: qkv read + out written (fwd)
+  gather_hbm             row gather of 819,200 x 768 bf16 rows (the config-3 batch: 2.5 GB working set, far beyond the
+                         256 MiB Infinity Cache): n (2 * 1536 + 4) bytes
+  scan                   config 5: 1,000,000 x 768 bf16 unit rows x 160 text rows -> sigmoid -> max/argmax: n (1536 + 8) bytes
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak
+
+
+def build(n_side=256, which=None):
+    """-> list of dict(name, kernel (substring of the HIP kernel name), run, bound, flops | bytes, note)."""
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.plan import build_plan
+    from scenesplat_amd.synthetic import room_chunk
+    data = room_chunk(n_side, 0, lang_dim=0)
+    plan = build_plan(data["grid_coord"].cuda(), data["offset"].cuda(), ("z", "z-trans", "hilbert", "hilbert-trans"), (2, 2, 2))
+    lv = plan.levels[0]
+    C, H, K = 768, 16, 1024
+    d = C // H
+    g = torch.Generator(device="cuda").manual_seed(0)
+    want = lambda k: which is None or k in which
+    probes = []
+    if want("conv_fwd") or want("conv_wgrad"):
+        nbr, perm, blocks = lv.neighbors(3), lv.conv_rowperm(), lv.conv_blocks(3)
+        x = torch.randn(lv.n, C, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(C, 27, C, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+        go = torch.randn(lv.n, C, device="cuda", generator=g).to(torch.bfloat16)
+        pairs = int((nbr >= 0).sum().item())
+        fl = 2.0 * pairs * C * C
+        by = lv.n * C * 2 * 2 + 27 * C * C * 2
+        note = "n=%d, C=%d, 27 taps, %.2f pairs/site" % (lv.n, C, pairs / lv.n)
+        if want("conv_fwd"):
+            probes.append(dict(name="conv_fwd", kernel="k_gemm8", run=lambda: nv.subm_conv_fwd(x, w, None, nbr, perm), bound="mfma",
+                               flops=fl, bytes=by, note="k_gemm8<true> subm conv fwd/dgrad (dec0: %s)" % note))
+        if want("conv_wgrad"):
+            probes.append(dict(name="conv_wgrad", kernel="k_wgrad8", run=lambda: nv.subm_conv_wgrad(x, go, nbr, perm, blocks), bound="mfma",
+                               flops=fl, bytes=2 * lv.n * C * 2 + 27 * C * C * 4, note="k_wgrad8<true> subm conv wgrad (dec0: %s)" % note))
+    if want("attn_fwd") or want("attn_bwd"):
+        win = lv.window(0, K)
+        qkv = torch.randn(lv.n, 3 * C, device="cuda", generator=g).to(torch.bfloat16)
+        dout = torch.randn(lv.n, C, device="cuda", generator=g).to(torch.bfloat16)
+        sc = d ** -0.5
+        out, lse = nv.window_attn_fwd(qkv, win, H, sc, nv.ATTN_MFMA)
+        fl = win.num_windows * H * 4.0 * K * K * d
+        note = "%d windows x %d heads, K=%d, d=%d" % (win.num_windows, H, K, d)
+        if want("attn_fwd"):
+            probes.append(dict(name="attn_fwd", kernel="k_attn_fwd", run=lambda: nv.window_attn_fwd(qkv, win, H, sc, nv.ATTN_MFMA), bound="mfma",
+                               flops=fl, bytes=lv.n * C * 2 * 4, note="window attention forward (dec0: %s)" % note))
+        if want("attn_bwd"):
+            probes.append(dict(name="attn_bwd", kernel="k_attn_bwd", run=lambda: nv.window_attn_bwd(qkv, out, dout, lse, win, H, sc, nv.ATTN_MFMA),
+                               bound="mfma", flops=2.5 * fl, bytes=lv.n * C * 2 * 8,
+                               note="window attention backward, dQ + dK/dV kernels (dec0: %s)" % note))
+    if want("gather_hbm"):
+        nb = 8 * lv.n
+        src = torch.randn(nb, C, device="cuda", generator=g).to(torch.bfloat16)
+        idx = torch.randperm(nb, device="cuda", generator=g).to(torch.int32)
+        dst = torch.empty_like(src)
+        probes.append(dict(name="gather_hbm", kernel="k_gather_rows", run=lambda: nv.gather_rows(src, idx, out=dst), bound="hbm",
+                           bytes=nb * (2 * C * 2 + 4), note="gather_rows(%d x %d bf16, random permutation; %.2f GB working set)" % (nb, C, 2 * nb * C * 2 / 1e9)))
+    if want("scan"):
+        n, cls = 1_000_000, 160
+        feat = torch.nn.functional.normalize(torch.randn(n, C, device="cuda", generator=g), dim=1).to(torch.bfloat16)
+        text = torch.nn.functional.normalize(torch.randn(cls, C, device="cuda", generator=g), dim=1).to(torch.bfloat16)
+        probes.append(dict(name="scan", kernel="k_feat_text_scan", run=lambda: nv.feat_text_scan(feat, text), bound="hbm",
+                           bytes=n * (C * 2 + 8), flops=2.0 * n * C * cls,
+                           note="open-vocabulary scan (config 5): %d x %d bf16 x %d classes -> sigmoid -> max/argmax" % (n, C, cls)))
+    return probes
+
+
+def time_probe(p, iters=5, warmup=2):
+    """Average launch duration in ms: HIP events on the stream the kernel is launched on (torch's current stream)."""
+    for _ in range(warmup):
+        p["run"]()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        p["run"]()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def roofline_entry(p, ms, traffic=None):
+    if p["bound"] == "mfma":
+        ach = p["flops"] / (ms * 1e-3) / 1e12
+        ent = dict(bound="mfma", kernel=p["note"], achieved=ach, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", frac=ach / MFMA_BF16_PEAK_TF,
+                   algorithmic_flops=p["flops"], algorithmic_bytes=p["bytes"])
+    else:
+        ach = p["bytes"] / (ms * 1e-3) / 1e9
+        ent = dict(bound="hbm", kernel=p["note"], achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                   algorithmic_bytes=p["bytes"])
+    ent["ms"] = ms
+    ent["traffic"] = traffic
+    ent["traffic_unit"] = "bytes/launch beyond the XCD L2s (rocprofv3 FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, measured in this run)"
+    return ent
+
+
+if __name__ == "__main__":
+    # PMC pass: every probe a few times (no timing here; the counters are per launch)
+    names = [a for a in sys.argv[1:] if not a.startswith("-")] or None
+    for p in build(which=names):
+        for _ in range(3):
+            p["run"]()
+        torch.cuda.synchronize()
+        print("probe", p["name"], "done", flush=True)

@@ -129,8 +129,11 @@ def test_subm_conv_fused_mfma_against_oracle(k, cin, cout, dup):
     yo = oops.subm_conv3d(xo, wo, bo, nbr)
     (yo * cot).sum().backward()
     xg, wg, bg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
-    y = SF.subm_conv3d(xg, wg, bg, lv.neighbors(k), lv.has_duplicates, torch.bfloat16, lv.conv_rowperm())
-    assert y.dtype == torch.bfloat16
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = SF.subm_conv3d(xg, wg, bg, lv.neighbors(k), lv.has_duplicates, torch.bfloat16, lv.conv_rowperm())
+    assert y.dtype == torch.bfloat16                     # under autocast the next op is a bf16 GEMM
+    with torch.no_grad():                                # outside autocast (evaluator call form): fp32 out for the fp32 Linear
+        assert SF.subm_conv3d(xg, wg, bg, lv.neighbors(k), lv.has_duplicates, torch.bfloat16, lv.conv_rowperm()).dtype == torch.float32
     (y.float() * cot.cuda()).sum().backward()
     def rel(a, r): return ((a.float().cpu() - r).norm() / r.norm()).item()
     assert rel(y, yo) < 6e-3, rel(y, yo)                 # bf16 output rounding
