@@ -25,6 +25,7 @@
 //   * LDS images are lane-linear (LDS-DMA writes base + lane*16); the XOR swizzle that makes ds_read_b128
 //     conflict-free is applied to the per-lane SOURCE chunk and again on the read.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/scenesplat_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 g8_bf8_t;
@@ -57,7 +58,7 @@ template <bool GATHER, typename OutT>
 __global__ void __launch_bounds__(512)
 k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, const float* __restrict__ bias,
         const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowperm, OutT* __restrict__ out, int M, int K,
-        int N, int taps, int ntn) {
+        int N, int taps, int ntn, int tap_inner) {
   __shared__ __attribute__((aligned(16))) char smem[G8_LDS_BYTES];   // ONE object: tiles + rulebook slice
   int32_t* nbr_s = reinterpret_cast<int32_t*>(smem + G8_OFF_NBR);
   int32_t* rowid_s = reinterpret_cast<int32_t*>(smem + G8_OFF_ROWID);
@@ -73,6 +74,7 @@ k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__
   const int m0 = (L / ntn) * 256, n0 = (L % ntn) * 256;
 
   unsigned rem = 0u;       // taps still to do after the current one (GATHER)
+  unsigned mask_all = 0u;  // the tile's active taps
   int tap = 0;
   if (GATHER) {
     if (tid < 256) {
@@ -90,6 +92,7 @@ k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__
     }
     __syncthreads();
     rem = __builtin_amdgcn_readfirstlane(*mask_s);
+    mask_all = rem;
   }
   const int ksteps = K >> 6;
   int T;                                        // K-tiles of this workgroup
@@ -142,6 +145,15 @@ k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__
   auto advance = [&]() {
     if (staged + 1 >= T) return;                 // past the end: keep re-staging the last tile (harmless, keeps vmcnt uniform)
     ++staged;
+    if (GATHER && tap_inner) {
+      // experiment (off by default, see g8_launch): channel chunk outer, tap inner -- the 64-channel pieces of the tile's
+      // rows are fetched for all active taps back to back so that re-reads hit the XCD's L2
+      if (rem == 0u) { kc += 64; rem = mask_all; }
+      tap = __builtin_ctz(rem); rem &= rem - 1u;
+      boff = (int64_t)tap * K;
+      load_rows(tap);
+      return;
+    }
     kc += 64;
     if (kc == K) {
       kc = 0;
@@ -282,13 +294,17 @@ template <bool GATHER>
 static int g8_launch(const void* a, const void* w, const float* bias, const int32_t* nbr, const int32_t* rowperm, void* out,
                      int64_t m, int k, int n, int taps, int out_dtype, hipStream_t stream) {
   if (!ss_gemm8_ok(m, k, n, taps)) return SS_ERR_ARG;
+  // SS_CONV_TAP_INNER=1 (diagnostic A/B switch, read once): channel-chunk-outer / tap-inner K walk.  Measured SLOWER at
+  // dec0 (1.03 -> 1.24 ms) and dec1 (0.23 -> 0.28 ms): the per-K-tile address rebuild and the scattered 128-byte row
+  // pieces cost more than the L2 re-use of the rows buys; the default stays tap-outer (rows streamed 1.5 KB at a time)
+  static const int tap_inner = [] { const char* e = getenv("SS_CONV_TAP_INNER"); return e ? atoi(e) : 0; }();
   const int ntm = ss_div_up(m, 256), ntn = ss_div_up(n, 256);
   dim3 grid(ntm * ntn), block(512);
   const unsigned short* A = (const unsigned short*)a; const unsigned short* Wp = (const unsigned short*)w;
   if (out_dtype == SS_BF16)
-    SS_LAUNCH((k_gemm8<GATHER, unsigned short>), grid, block, 0, stream, A, Wp, bias, nbr, rowperm, (unsigned short*)out, (int)m, k, n, taps, ntn);
+    SS_LAUNCH((k_gemm8<GATHER, unsigned short>), grid, block, 0, stream, A, Wp, bias, nbr, rowperm, (unsigned short*)out, (int)m, k, n, taps, ntn, tap_inner);
   else if (out_dtype == SS_F32)
-    SS_LAUNCH((k_gemm8<GATHER, float>), grid, block, 0, stream, A, Wp, bias, nbr, rowperm, (float*)out, (int)m, k, n, taps, ntn);
+    SS_LAUNCH((k_gemm8<GATHER, float>), grid, block, 0, stream, A, Wp, bias, nbr, rowperm, (float*)out, (int)m, k, n, taps, ntn, tap_inner);
   else
     return SS_ERR_ARG;
   return SS_OK;

@@ -8,8 +8,11 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
-#define SC_THREADS 256
-#define SC_BM 128      // rows per workgroup: 4 waves x 32
+#ifndef SC_WAVES
+#define SC_WAVES 8     // 8 waves x 32 rows: the text tile of a K step is staged once per 256 Gaussians
+#endif
+#define SC_THREADS (64 * SC_WAVES)
+#define SC_BM (32 * SC_WAVES)      // rows per workgroup
 #define SC_BK 64
 
 __device__ __forceinline__ int sc_row_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -116,7 +119,9 @@ extern "C" int ss_feat_text_scan(const void* feat_bf16, const void* text_bf16, i
   const unsigned short* f = (const unsigned short*)feat_bf16; const unsigned short* t = (const unsigned short*)text_bf16;
   const int nt = (num_classes + 15) / 16;
 #define SS_SCAN(NTN) SS_LAUNCH(k_feat_text_scan<NTN>, g, b, 0, stream, f, t, n, dim, num_classes, max_prob, argmax, idx, pred_accum)
-  if (nt <= 2) SS_SCAN(2); else if (nt <= 4) SS_SCAN(4); else if (nt <= 8) SS_SCAN(8); else if (nt <= 13) SS_SCAN(13); else SS_SCAN(16);
+  // exact tile counts for the label sets of the reference (20 / 21 classes: 2, 100: 7, 160: 10, 200: 13)
+  if (nt <= 2) SS_SCAN(2); else if (nt <= 4) SS_SCAN(4); else if (nt <= 7) SS_SCAN(7); else if (nt <= 8) SS_SCAN(8);
+  else if (nt <= 10) SS_SCAN(10); else if (nt <= 13) SS_SCAN(13); else SS_SCAN(16);
 #undef SS_SCAN
   return SS_OK;
 }

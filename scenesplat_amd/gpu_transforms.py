@@ -32,3 +32,87 @@ def grid_sample_train(coord, grid_size, generator=None, return_inverse=False):
     if return_inverse:
         out["inverse"] = cluster.long()
     return out
+
+
+def _take_rows(t, idx32):
+    """t[idx] for a per-point tensor: wide contiguous rows go through the library's row-gather kernel."""
+    if t.dim() == 2 and t.is_contiguous() and (t.shape[1] * t.element_size()) % 16 == 0 and t.dtype in (torch.float32, torch.bfloat16, torch.float16):
+        return nv.gather_rows(t, idx32)
+    return t[idx32.long()]
+
+
+@torch.no_grad()
+def sphere_crop(data_dict, point_max=80000, sample_rate=None, mode="random", generator=None):
+    """SphereCrop(mode="random" | "center") on the device (pointcept/datasets/transform.py:1420-1548): when the sample has
+    more than point_max points keep the point_max points nearest to a centre point -- a uniformly random point, or the
+    middle row -- in ascending distance order (ties by row index).  The distance sort is the library's stable radix
+    argsort on the float bit pattern (squared distances are non-negative, so the IEEE bits are order-preserving).
+    Every per-point tensor of the dict (first dimension N) is cropped; the reference enumerates the SceneSplat keys
+    coord / origin_coord / grid_coord / color / quat / scale / opacity / normal / lang_feat / valid_feat_mask / segment /
+    instance / displacement / strength, which are exactly the per-point entries its datasets produce."""
+    if mode not in ("random", "center"):
+        raise NotImplementedError('sphere_crop: mode must be "random" or "center" (mode "all" is the tester\'s CPU fragment loop)')
+    coord = data_dict["coord"]
+    if not coord.is_cuda:
+        raise RuntimeError("sphere_crop: GPU tensors required (no CPU fallback)")
+    n = coord.shape[0]
+    pm = int(sample_rate * n) if sample_rate is not None else int(point_max)
+    if n <= pm:
+        return data_dict
+    if mode == "random":
+        ci = int(torch.randint(0, n, (1,), generator=generator, device=coord.device if generator is not None and generator.device.type == "cuda" else "cpu"))
+    else:
+        ci = n // 2
+    d2 = (coord - coord[ci]).square().sum(1).float().contiguous()
+    key = d2.view(torch.int32).to(torch.int64).unsqueeze(0).contiguous()
+    order, _, _ = nv.argsort_i64(key, 32, want_inverse=False, want_sorted=False)
+    idx = order[0, :pm].contiguous()
+    out = dict(data_dict)
+    for k, v in data_dict.items():
+        if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == n:
+            out[k] = _take_rows(v, idx)
+    return out
+
+
+@torch.no_grad()
+def collect(data_dict, keys, offset_keys_dict=None, **kwargs):
+    """Collect (transform.py:320-352): pick `keys`, record `offset` = number of points of `coord`, and build every
+    `<name>_keys=(...)` entry as the float32 column-concatenation of the listed tensors, e.g.
+    feat_keys=("color", "opacity", "quat", "scale") -> feat (N, 11) for the SceneSplat language configs."""
+    if isinstance(keys, str):
+        keys = [keys]
+    offset_keys = dict(offset="coord") if offset_keys_dict is None else offset_keys_dict
+    data = {k: data_dict[k] for k in keys if k in data_dict}
+    for k, v in offset_keys.items():
+        data[k] = torch.tensor([data_dict[v].shape[0]], device=data_dict[v].device)
+    for name, ks in kwargs.items():
+        data[name.replace("_keys", "")] = torch.cat([data_dict[k].float() for k in ks], dim=1)
+    return data
+
+
+@torch.no_grad()
+def point_collate(batch, mix_prob=0.0, rng=None):
+    """point_collate_fn (pointcept/datasets/utils.py:8-48) for a list of per-sample dicts of device tensors: tensors are
+    concatenated along the points, every key containing "offset" becomes the running total, strings are listed, scalars
+    stacked; with probability mix_prob (host RNG, as the reference) Mix3D merges neighbouring samples pairwise by keeping
+    every second offset (the merged element then holds duplicate voxels, which the plan tolerates)."""
+    import random
+    if not batch or not isinstance(batch[0], dict):
+        raise TypeError("point_collate expects a list of dicts")
+    out = {}
+    for key in batch[0]:
+        vals = [d[key] for d in batch]
+        v0 = vals[0]
+        if isinstance(v0, torch.Tensor):
+            out[key] = torch.cat([v if v.dim() > 0 else v.reshape(1) for v in vals])
+        elif isinstance(v0, str):
+            out[key] = list(vals)
+        else:
+            out[key] = torch.as_tensor(vals)
+    for key in out:
+        if "offset" in key:
+            out[key] = torch.cumsum(out[key], dim=0)
+    if "offset" in out and (rng or random).random() < mix_prob:
+        off = out["offset"]
+        out["offset"] = torch.cat([off[1:-1:2], off[-1:]], dim=0)
+    return out

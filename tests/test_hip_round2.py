@@ -285,3 +285,48 @@ def test_ddp_two_ranks_on_the_hip_model_end_with_identical_weights():
     for k in res[0][1]:
         assert np.array_equal(res[0][1][k], res[1][1][k]), k
     assert all(np.isfinite(v).all() for v in res[0][1].values())
+
+
+# ---- GPU data fast path: SphereCrop / Collect / collate -----------------------------------------
+def test_gpu_sphere_crop_collect_collate_against_reference_semantics():
+    """pointcept/datasets/transform.py:1420-1548 (SphereCrop random / center), :320-352 (Collect) and
+    datasets/utils.py:8-48 (point_collate_fn + Mix3D) restated in numpy and compared with the device versions."""
+    import random
+    from scenesplat_amd import gpu_transforms as T
+    g = torch.Generator().manual_seed(0)
+    n = 5000
+    d = dict(coord=torch.rand(n, 3, generator=g) * 4, color=torch.rand(n, 3, generator=g), opacity=torch.rand(n, 1, generator=g),
+             quat=torch.randn(n, 4, generator=g), scale=torch.rand(n, 3, generator=g), lang_feat=torch.randn(n, 768, generator=g),
+             valid_feat_mask=torch.rand(n, generator=g) < 0.9, segment=torch.randint(-1, 20, (n,), generator=g), name="scene0")
+    dg = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in d.items()}
+    out = T.sphere_crop(dg, point_max=1500, mode="center")
+    cg = dg["coord"]
+    # distances evaluated with the same fp32 arithmetic as the device (a different summation order could swap near-ties)
+    dist2 = lambda ci: (cg - cg[ci]).square().sum(1).float().cpu().numpy()
+    idx = np.argsort(dist2(n // 2), kind="stable")[:1500]                                 # transform.py:1513-1517
+    for k in ("coord", "color", "opacity", "quat", "scale", "lang_feat", "valid_feat_mask", "segment"):
+        assert torch.equal(out[k].cpu(), d[k][torch.from_numpy(idx)]), k
+    assert out["name"] == "scene0"
+    assert T.sphere_crop(dg, point_max=6000)["coord"] is dg["coord"]                      # small samples pass through
+    out = T.sphere_crop(dg, sample_rate=0.25, mode="random", generator=torch.Generator().manual_seed(5))
+    ci = int(torch.randint(0, n, (1,), generator=torch.Generator().manual_seed(5)))
+    idx = np.argsort(dist2(ci), kind="stable")[:n // 4]
+    assert torch.equal(out["coord"].cpu(), d["coord"][torch.from_numpy(idx)])
+    # Collect: keys + offset + feat = cat(color, opacity, quat, scale) (configs/...contrastive.py:93)
+    col = T.collect(out, keys=("coord", "segment", "lang_feat", "valid_feat_mask"), feat_keys=("color", "opacity", "quat", "scale"))
+    assert set(col) == {"coord", "segment", "lang_feat", "valid_feat_mask", "offset", "feat"}
+    assert col["feat"].shape == (n // 4, 11) and int(col["offset"][0]) == n // 4
+    assert torch.equal(col["feat"], torch.cat([out[k].float() for k in ("color", "opacity", "quat", "scale")], 1))
+    # collate 4 samples; Mix3D keeps every second offset (utils.py:44-47)
+    samples = []
+    for i, m in enumerate((300, 500, 200, 400)):
+        samples.append(dict(coord=out["coord"][:m], feat=col["feat"][:m], offset=torch.tensor([m], device="cuda"), name="s%d" % i))
+    b = T.point_collate(samples, mix_prob=0.0)
+    assert b["offset"].tolist() == [300, 800, 1000, 1400] and b["coord"].shape[0] == 1400 and b["name"] == ["s0", "s1", "s2", "s3"]
+    b = T.point_collate(samples, mix_prob=1.0, rng=random.Random(0))
+    assert b["offset"].tolist() == [800, 1400]
+    # and the collated Mix3D batch runs through the planner (duplicate voxels tolerated)
+    from scenesplat_amd.plan import build_plan
+    gc = torch.floor(b["coord"] / 0.02).int()
+    plan = build_plan(gc - gc.amin(0, keepdim=True), b["offset"], ("z", "hilbert"), (2,))
+    assert plan.levels[0].n == 1400
