@@ -213,6 +213,15 @@ def secondary_lines(log, steps=3):
         out["conv_fp32_reference_precision"] = dict(metric="Gaussians/s encoder fwd+bwd, 102k-pt chunk, submanifold conv with fp32 operands (reference semantics), other GEMMs bf16",
                                                     value=data["feat"].shape[0] / dt, unit="Gaussians/s", ms_per_step=dt * 1e3, steps=steps,
                                                     dtype="bf16 autocast + fp32 conv")
+        del model
+        gc.collect(); torch.cuda.empty_cache()
+        RUNTIME["conv_dtype"] = "bf16x3"      # the same precision on the MFMA kernels (hi/lo-split operands, 3x the conv FLOPs)
+        torch.manual_seed(1)
+        model = MODELS.build(dict(type="PT-v3m1", **LANG_PTV3)).cuda().train()
+        dt = run(model, model, data, False, "conv bf16x3 (reference precision on MFMA)", steps)
+        out["conv_bf16x3_reference_precision_mfma"] = dict(metric="Gaussians/s encoder fwd+bwd, 102k-pt chunk, submanifold conv on hi/lo-split bf16 operands (near-fp32 result), other GEMMs bf16",
+                                                           value=data["feat"].shape[0] / dt, unit="Gaussians/s", ms_per_step=dt * 1e3, steps=steps,
+                                                           dtype="bf16 autocast + bf16x3 conv")
         del model, data
         gc.collect(); torch.cuda.empty_cache()
     except Exception as e:   # noqa: BLE001  (secondary lines must never take the headline down)

@@ -225,6 +225,61 @@ class _SubMConv3dFused(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+def _split_bf16(t):
+    """t (fp32) -> (hi, lo) bf16 with hi + lo = t to ~2^-17 relative (hi = RNE(t), lo = RNE(t - hi))."""
+    t = t.float()
+    hi = t.to(torch.bfloat16)
+    return hi, (t - hi.float()).to(torch.bfloat16)
+
+
+class _SubMConv3dSplit(torch.autograd.Function):
+    """Submanifold conv at (near) fp32 precision ON THE MFMA KERNELS: the reference keeps this one op in fp32 under AMP
+    (pointcept/models/modules.py:64-75); bf16 operands cost ~2e-5 of per-Gaussian cosine distance on the full model, the
+    per-tap fp32 path is 8x slower.  Both operands are split into bf16 hi + lo parts and the product is evaluated as
+    xh wh + xl wh + xh wl (the dropped xl wl term is ~2^-18 relative) -- as ONE fused launch on channel-concatenated operands
+    [xh | xl | xh] x [wh | wh | wl], fp32 accumulate, fp32 out.  dgrad uses the same form on (g, mirrored w); wgrad is
+    (xh + xl) (x) gh + xh (x) gl.  3x the conv FLOPs of the bf16 mode."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias, nbr, rowperm, blocks_fn):
+        taps, n = nbr.shape
+        cout, cin = weight.shape[0], weight.shape[-1]
+        pad = (-cin) % 8
+        x = feat.float()
+        w = weight.float().reshape(cout, taps, cin)
+        if pad:
+            x = torch.nn.functional.pad(x, (0, pad)); w = torch.nn.functional.pad(w, (0, pad))
+        xh, xl = _split_bf16(x)
+        wh, wl = _split_bf16(w)
+        x3 = torch.cat([xh, xl, xh], 1).contiguous()
+        w3 = torch.cat([wh, wh, wl], 2).contiguous()
+        out = nv.subm_conv_fwd(x3, w3, None if bias is None else bias.float().contiguous(), nbr, rowperm, torch.float32)
+        ctx.save_for_backward(xh, xl, wh, wl, nbr, rowperm)
+        ctx.meta = (feat.dtype, weight.dtype, weight.shape, cin, bias is not None)
+        ctx.blocks_fn = blocks_fn
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xh, xl, wh, wl, nbr, rowperm = ctx.saved_tensors
+        in_dtype, w_dtype, w_shape, cin, has_bias = ctx.meta
+        gh, gl = _split_bf16(dout.contiguous())
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt3 = torch.cat([nv.subm_weight_mirror(wh), nv.subm_weight_mirror(wh), nv.subm_weight_mirror(wl)], 2).contiguous()
+            g3 = torch.cat([gh, gl, gh], 1).contiguous()
+            dx = nv.subm_conv_fwd(g3, wt3, None, nbr, rowperm, torch.float32)[:, :cin].to(in_dtype)
+        if ctx.needs_input_grad[1]:
+            blocks = ctx.blocks_fn() if ctx.blocks_fn is not None else nv.subm_block_lists(nbr, rowperm)
+            cp = xh.shape[1]
+            d2 = nv.subm_conv_wgrad(torch.cat([xh, xl], 1).contiguous(), gh, nbr, rowperm, blocks)      # (cout, taps, 2 cp)
+            d1 = nv.subm_conv_wgrad(xh, gl, nbr, rowperm, blocks)
+            dw = (d2[:, :, :cp] + d2[:, :, cp:] + d1)[:, :, :cin].reshape(w_shape).to(w_dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dout.sum(0, dtype=torch.float32).to(w_dtype)
+        return dx, dw, db, None, None, None
+
+
 CONV_IM2COL_MAX_SITES = int(os.environ.get("SS_CONV_IM2COL_MAX", "8192"))
 
 
@@ -238,9 +293,14 @@ def _mm_f32(a, b):
 
 def subm_conv3d(feat, weight, bias, nbr, has_dup=False, compute_dtype=torch.float32, rowperm=None, blocks_fn=None):
     """weight (Cout, k, k, k, Cin) as in the reference checkpoints; nbr (k^3, n) tap-major.
-    bf16 compute on unique voxels -> fused MFMA kernels; otherwise per-tap gather + GEMM."""
+    compute_dtype: torch.bfloat16 -> fused MFMA kernels on bf16 operands; "bf16x3" -> the same kernels on hi/lo-split
+    operands (near-fp32 result, the reference's precision for this op); torch.float32 -> per-tap gather + fp32 GEMM."""
     if compute_dtype == torch.bfloat16 and weight.shape[0] % 8 == 0:
         return _SubMConv3dFused.apply(feat, weight, bias, nbr, rowperm, blocks_fn, has_dup)
+    if compute_dtype == "bf16x3":
+        if weight.shape[0] % 8 == 0 and not has_dup and feat.is_cuda:
+            return _SubMConv3dSplit.apply(feat, weight, bias, nbr, rowperm, blocks_fn)
+        compute_dtype = torch.float32            # duplicate voxels (Mix3D) / odd widths: the per-tap fp32 path
     return _SubMConv3d.apply(feat, weight, bias, nbr, has_dup, compute_dtype)
 
 

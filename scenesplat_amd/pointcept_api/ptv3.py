@@ -29,7 +29,7 @@ from .registry import MODELS
 from .structure import Point
 
 # knobs of the execution (not of the model): attention kernel family and conv compute dtype
-RUNTIME = dict(attn_impl=nv.ATTN_SIMT, conv_dtype=None,  # conv_dtype None: follow the reference (fp32)
+RUNTIME = dict(attn_impl=nv.ATTN_SIMT, conv_dtype=None,  # conv_dtype: None = fp32 per-tap path (reference), torch.bfloat16, or "bf16x3"
                param_shadows=os.environ.get("SS_PARAM_SHADOWS", "1") != "0")   # bf16 weight shadows under autocast
 
 

@@ -43,6 +43,7 @@ ladder = [("fp32 everywhere (SIMT attn, fp32 conv)", False, dict(attn_impl=nv.AT
           ("bf16 conv only (no autocast)", False, dict(attn_impl=nv.ATTN_SIMT, conv_dtype=torch.bfloat16)),
           ("autocast, fp32 conv, SIMT attn", True, dict(attn_impl=nv.ATTN_SIMT, conv_dtype=None)),
           ("autocast, fp32 conv, MFMA attn", True, dict(attn_impl=nv.ATTN_MFMA, conv_dtype=None)),
+          ("autocast, bf16x3 conv, MFMA attn", True, dict(attn_impl=nv.ATTN_MFMA, conv_dtype="bf16x3")),
           ("autocast, bf16 conv, MFMA attn (bench)", True, dict(attn_impl=nv.ATTN_MFMA, conv_dtype=torch.bfloat16))]
 extra = [a for a in sys.argv[1:] if a.startswith("rt:")]
 for e in extra:      # e.g. rt:conv_out_fp32=1

@@ -1,6 +1,7 @@
 """Production-shape golden vectors from the REFERENCE's own Python (container only).
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_prod.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_prod.py            # attention_prod, ptv3_lang_prod
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_prod.py --full     # ptv3_lang_full (about 20 GB of memory)
 
 Same import recipe as make_golden.py (four third-party packages stubbed; spconv / torch_scatter
 arithmetic comes from the oracle and stays "parity unpinned").  What is new is the SHAPE: the
@@ -34,12 +35,45 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
-from prod_inputs import ATT, GRAD_KEYS, ORD, POOL_SEED, att_inputs, lang_inputs, proj, row_subset  # noqa: E402
+from prod_inputs import ATT, GRAD_KEYS, ORD, POOL_SEED, att_inputs, full_inputs, lang_inputs, proj, row_subset  # noqa: E402
+
+
+def full_size(ptv3, optv3):
+    """ptv3_lang_full.npz: the reference model's FORWARD on the benchmark's own workload shape (room-102400, levels
+    102400/25600/6400/1600, 100 windows of 1024 at dec0), eval-BN and train-BN, under no_grad (the non-flash reference
+    attention materialises 6.7 GB of scores per dec0 block; a backward pass would not fit this container's memory).
+    Stored: 1,536 rows in fp16 + an fp32 projection and the norm of every row."""
+    cfg = dict(optv3.DEFAULT_CFG)
+    model = ptv3.PointTransformerV3(**cfg, drop_path=0.0, shuffle_orders=False, enable_flash=False,
+                                    upcast_attention=False, upcast_softmax=False, enable_rpe=False)
+    sd0 = optv3.init_state_dict(cfg, seed=5)
+    gc, feat = full_inputs()
+    n = len(gc)
+    assert n == 102400
+    rows = row_subset(n, 1536, seed=99)
+    fx = {"rows": rows.numpy(), "n": np.int64(n)}
+    for mode in ("eval", "train"):
+        model.load_state_dict(sd0)
+        model.train(mode == "train")
+        torch.manual_seed(POOL_SEED)
+        with torch.no_grad():
+            y = model(dict(coord=gc.float() * 0.02, grid_coord=gc, feat=feat, offset=torch.tensor([n]))).feat
+        fx[f"{mode}_y_rows"] = y[rows].half().numpy()
+        fx[f"{mode}_y_proj"] = proj(y).numpy()
+        fx[f"{mode}_y_norm"] = y.norm(dim=1).numpy()
+        print(f"ptv3_lang_full[{mode}]: |y| mean %.3f" % float(y.norm(dim=1).mean()), flush=True)
+        del y
+    np.savez_compressed(os.path.join(HERE, "ptv3_lang_full.npz"), **fx)
+    print("ptv3_lang_full.npz", os.path.getsize(os.path.join(HERE, "ptv3_lang_full.npz")) // 1024, "KiB")
 
 
 def main():
     import make_golden as mg
     mg.install_stubs()
+    if "--full" in sys.argv:
+        ptv3_ = importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m1_base")
+        from oracle import ptv3 as optv3_
+        return full_size(ptv3_, optv3_)
     ptv3 = importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m1_base")
     from pointcept.models.utils.structure import Point
     from oracle import ptv3 as optv3

@@ -65,3 +65,19 @@ def lang_inputs():
     feat = torch.cat([color, opacity, quat, scale], 1)
     cot = torch.randn(n, 768, generator=g)
     return gc, feat, cot
+
+
+FULL_SIDE = 256                  # the benchmark's room-102400 workload itself
+
+
+def full_inputs():
+    """Seeded inputs of the FULL-SIZE fixture ptv3_lang_full.npz: one 102,400-Gaussian room chunk (the shape bench.py
+    times), weights oracle.ptv3.init_state_dict(cfg, seed=5)."""
+    gc = torch.from_numpy(room(FULL_SIDE, 0))
+    n = len(gc)
+    g = torch.Generator().manual_seed(16)
+    color = torch.rand(n, 3, generator=g) * 2 - 1
+    opacity = torch.rand(n, 1, generator=g)
+    quat = torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=1)
+    scale = torch.rand(n, 3, generator=g) * 1.5
+    return gc, torch.cat([color, opacity, quat, scale], 1)
