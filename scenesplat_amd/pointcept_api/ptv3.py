@@ -35,8 +35,21 @@ RUNTIME = dict(attn_impl=nv.ATTN_SIMT, conv_dtype=None,  # conv_dtype: None = fp
 
 def bench_runtime():
     """The execution knobs bench.py times (and tests/test_hip_prod.py holds to the north-star cosine bar): MFMA window
-    attention and bf16 operands for the submanifold conv, under torch bf16 autocast."""
-    return dict(attn_impl=nv.ATTN_MFMA, conv_dtype=torch.bfloat16)
+    attention; submanifold conv on bf16 operands -- except the 32-channel stage (stem + the two enc0 blocks), which runs on
+    hi/lo-split operands ("bf16x3", the reference's fp32 precision for this op).  Rounding the conv operands of the FIRST
+    stage is what cost the cosine budget (it propagates through all 22 blocks): split there, the training-mode maximum
+    drops from 1.0e-4 to 7e-5 for +0.8 ms per step; splitting every stage up to 256 channels buys 0.5e-5 more for +3.8 ms
+    (scripts/prec_probe.py --split-sweep).  All under torch bf16 autocast."""
+    return dict(attn_impl=nv.ATTN_MFMA, conv_dtype=torch.bfloat16,
+                conv_split_max_channels=int(os.environ.get("SS_CONV_SPLIT_MAX", "32")))
+
+
+def conv_dtype_for(out_channels):
+    """RUNTIME["conv_dtype"] for a conv of this width: bf16 convs up to conv_split_max_channels run as "bf16x3"."""
+    cd = RUNTIME["conv_dtype"] or torch.float32
+    if cd == torch.bfloat16 and out_channels <= RUNTIME.get("conv_split_max_channels", 0):
+        return "bf16x3"
+    return cd
 
 
 class PointModule(nn.Module):
@@ -72,7 +85,7 @@ class SubMConv3d(nn.Module):
         nn.init.kaiming_uniform_(self.weight.view(out_channels, -1), a=5 ** 0.5)
 
     def forward(self, feat, level):
-        cd = RUNTIME["conv_dtype"] or torch.float32
+        cd = conv_dtype_for(self.weight.shape[0])
         return SF.subm_conv3d(feat, self.weight, self.bias, level.neighbors(self.kernel_size),
                               level.has_duplicates, cd, level.conv_rowperm(),
                               lambda: level.conv_blocks(self.kernel_size))
@@ -429,7 +442,7 @@ class PointTransformerV3(PointModule):
         else:
             offset = point["offset"]  # derived lazily from batch
         # the fused conv consumes bf16: let each block hand the next one a bf16 copy of the residual stream
-        self._want_copy = (RUNTIME["conv_dtype"] == torch.bfloat16)
+        self._want_copy = (RUNTIME["conv_dtype"] == torch.bfloat16)      # per stage: only where the conv takes plain bf16 operands
         # bf16 operands are consumed under autocast (Linear) and whenever the conv runs in bf16 -- also without autocast
         # (the evaluator's no_grad / chunk_size call): refresh in both cases.  Shadows are version-stamped
         # (SF.bf16_of), so a forward that skips the refresh casts afresh instead of reading stale weights.
@@ -455,7 +468,8 @@ class PointTransformerV3(PointModule):
                 x = enc.down(x, levels[s])
             xb = None
             for i in range(self.enc_depths[s]):
-                x, xb = getattr(enc, f"block{i}")(x, x if xb is None else xb, levels[s], self._want_copy and i + 1 < self.enc_depths[s])
+                wc = self._want_copy and conv_dtype_for(x.shape[1]) == torch.bfloat16
+                x, xb = getattr(enc, f"block{i}")(x, x if xb is None else xb, levels[s], wc and i + 1 < self.enc_depths[s])
         lv = self.num_stages - 1
         if not self.cls_mode:
             for s in reversed(range(self.num_stages - 1)):
@@ -465,8 +479,9 @@ class PointTransformerV3(PointModule):
                     x = SF.defer_marker(x)       # backward leaves the full-resolution stage here: launch its queued wgrads
                 xb = None
                 for i in range(self.dec_depths[s]):
+                    wc = self._want_copy and conv_dtype_for(x.shape[1]) == torch.bfloat16
                     x, xb = getattr(dec, f"block{i}")(x, conv_in if i == 0 else (x if xb is None else xb), levels[s],
-                                                      self._want_copy and i + 1 < self.dec_depths[s])
+                                                      wc and i + 1 < self.dec_depths[s])
             lv = 0
             if self.training:
                 SF.defer_open()                  # backward starts in dec0: queue its weight gradients (see SF._Defer)

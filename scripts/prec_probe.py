@@ -44,7 +44,12 @@ ladder = [("fp32 everywhere (SIMT attn, fp32 conv)", False, dict(attn_impl=nv.AT
           ("autocast, fp32 conv, SIMT attn", True, dict(attn_impl=nv.ATTN_SIMT, conv_dtype=None)),
           ("autocast, fp32 conv, MFMA attn", True, dict(attn_impl=nv.ATTN_MFMA, conv_dtype=None)),
           ("autocast, bf16x3 conv, MFMA attn", True, dict(attn_impl=nv.ATTN_MFMA, conv_dtype="bf16x3")),
-          ("autocast, bf16 conv, MFMA attn (bench)", True, dict(attn_impl=nv.ATTN_MFMA, conv_dtype=torch.bfloat16))]
+          ("autocast, bf16 conv everywhere, MFMA attn", True, dict(attn_impl=nv.ATTN_MFMA, conv_dtype=torch.bfloat16, conv_split_max_channels=0)),
+          ("bench: bf16 conv C>256, bf16x3 below", True, dict(attn_impl=nv.ATTN_MFMA, conv_dtype=torch.bfloat16, conv_split_max_channels=256)),
+          ("bf16 conv C>512 only, bf16x3 below", True, dict(attn_impl=nv.ATTN_MFMA, conv_dtype=torch.bfloat16, conv_split_max_channels=512))]
+if "--split-sweep" in sys.argv:
+    ladder = [("bf16 conv, bf16x3 for C <= %d" % t, True, dict(attn_impl=nv.ATTN_MFMA, conv_dtype=torch.bfloat16, conv_split_max_channels=t))
+              for t in (0, 32, 64, 128, 256)]
 extra = [a for a in sys.argv[1:] if a.startswith("rt:")]
 for e in extra:      # e.g. rt:conv_out_fp32=1
     k, v = e[3:].split("=")
