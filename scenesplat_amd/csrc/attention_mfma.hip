@@ -106,7 +106,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {   // bijective: bloc
 #ifndef FA_PREFETCH2
 #define FA_PREFETCH2 0   // 1: two register stages (tile requested two steps ahead); measured neutral, costs 12-18 VGPRs
 #endif
-#define FA_IDX_CAP SS_ATTN_MFMA_MAX_WINDOW   // longest window whose gather rows fit the LDS copy (launchers refuse longer ones)
+#define FA_IDX_CAP SS_ATTN_MFMA_MAX_WINDOW
+#ifndef FA_ABL
+#define FA_ABL 0   // ablation bitmask of scripts/ubench/attn_bwd_bench.hip (diagnostic builds only)
+#endif   // longest window whose gather rows fit the LDS copy (launchers refuse longer ones)
 
 // stage a 64-row K/V tile (rows gidx[p0+r0 .. +63], column block `colofs`) into registers
 // gidx_w: the window's gather rows, copied to LDS once per workgroup (FA_IDX_CAP) -- a per-step global index load
@@ -381,10 +384,61 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
   const int p0 = win_start[w], L = win_start[w + 1] - p0;
   const int q0 = qc * FA_BQ;
   if (q0 >= L) return;
-  for (int i = tid; i < L; i += FA_THREADS) gidx_s[i] = (int32_t)((uint32_t)gidx[p0 + i] * (uint32_t)(3 * C >> 3));
-  __syncthreads();
+  // ---- prologue in TWO dependent rounds of global loads (it was five: index copy | barrier | query indices | query rows
+  // | first tile): a workgroup lives ~40 us and spent a third of it here (dQ 0.84 -> 0.57 ms with the row loads removed).
+  // round 1 -- everything addressed by p0 alone: the window's gather offsets, this lane's query indices and lse, and the
+  // row indices of this thread's chunks of the first K / V tile
   const int64_t C3 = 3 * (int64_t)C;
   const float c2 = scale * 1.44269504088896340736f;
+  constexpr int NFILL = FA_IDX_CAP / FA_THREADS;
+  int32_t fillv[NFILL];
+#pragma unroll
+  for (int k = 0; k < NFILL; ++k) { const int i = tid + k * FA_THREADS; fillv[k] = i < L ? gidx[p0 + i] : 0; }
+  int64_t qrow[FA_NT];
+  float lse2[FA_NT], dl[FA_NT];
+  int32_t srow[FA_NT];
+#pragma unroll
+  for (int qt = 0; qt < FA_NT; ++qt) {
+    const int slot = q0 + wave * FA_WQ + qt * 16 + lq;
+    const bool ok = slot < L;
+    qrow[qt] = ok ? gidx[p0 + slot] : -1;
+    srow[qt] = ok ? sidx[p0 + slot] : -1;
+    lse2[qt] = ok ? lse[(int64_t)(p0 + slot) * H + h] * 1.44269504088896340736f : 0.f;
+  }
+  uint32_t t0off[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int c = i * FA_THREADS + tid;
+    const int cc = c >= 64 * A::CH ? c - 64 * A::CH : c;
+    t0off[i] = (uint32_t)gidx[p0 + min(cc / A::CH, L - 1)] * (uint32_t)(3 * C >> 3);
+  }
+  // round 2 -- the rows those indices name: Q, dO, O of the wave's queries and the first K / V tile
+  uint4 qv[FA_NT][A::NKS], gv[FA_NT][A::NKS], ov[FA_NT][A::NKS];
+#pragma unroll
+  for (int qt = 0; qt < FA_NT; ++qt)
+#pragma unroll
+    for (int ks = 0; ks < A::NKS; ++ks) {
+      const int d0 = 32 * ks + 8 * g;
+      qv[qt][ks] = gv[qt][ks] = ov[qt][ks] = make_uint4(0, 0, 0, 0);
+      if (qrow[qt] >= 0 && d0 < D && !(FA_ABL & 128)) qv[qt][ks] = ld16(qkv + qrow[qt] * C3 + h * D + d0);
+      if (srow[qt] >= 0 && d0 < D && !(FA_ABL & 128)) {
+        gv[qt][ks] = ld16(dout + (int64_t)srow[qt] * C + h * D + d0); ov[qt][ks] = ld16(outp + (int64_t)srow[qt] * C + h * D + d0);
+      }
+    }
+  uint4 stA[NLD], stB[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int c = i * FA_THREADS + tid;
+    const int second = c >= 64 * A::CH;
+    const int cc = second ? c - 64 * A::CH : c;
+    const int ch = cc - (cc / A::CH) * A::CH;
+    stA[i] = make_uint4(0, 0, 0, 0);
+    if ((2 * 64 * A::CH) % FA_THREADS == 0 || c < 2 * 64 * A::CH)
+      stA[i] = ld16(reinterpret_cast<const char*>(qkv + (second ? 2 * C : C) + h * D + ch * 8) + ((uint64_t)t0off[i] << 4));
+  }
+  // LDS: gather offsets (16-byte units), contraction padding; the barrier also retires round 2
+#pragma unroll
+  for (int k = 0; k < NFILL; ++k) { const int i = tid + k * FA_THREADS; if (i < L) gidx_s[i] = (int32_t)((uint32_t)fillv[k] * (uint32_t)(3 * C >> 3)); }
   if (A::CHP > A::CH) {
     for (int e = tid; e < 4 * 64 * (A::CHP - A::CH); e += FA_THREADS) {
       int img = e / (64 * (A::CHP - A::CH)); int r = (e / (A::CHP - A::CH)) % 64; int ch = A::CH + e % (A::CHP - A::CH);
@@ -394,27 +448,20 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
       *reinterpret_cast<uint4*>(base + row_img_off<D>(r, ch)) = make_uint4(ch == A::CH ? 0x3F803F80u : 0u, 0, 0, 0);
     }
   }
+  __syncthreads();
   constexpr bool PAD = A::CHP > A::CH;
   constexpr int PADKS = D / 32, PADG = (D % 32) / 8;
   bf8_t qf[FA_NT][A::NKS], gf[FA_NT][A::NKS];
-  float lse2[FA_NT], dl[FA_NT];
-  int32_t srow[FA_NT];
 #pragma unroll
   for (int qt = 0; qt < FA_NT; ++qt) {
-    int slot = q0 + wave * FA_WQ + qt * 16 + lq;
-    bool ok = slot < L;
-    int64_t row = ok ? gidx[p0 + slot] : -1;
-    srow[qt] = ok ? sidx[p0 + slot] : -1;
-    lse2[qt] = ok ? lse[(int64_t)(p0 + slot) * H + h] * 1.44269504088896340736f : 0.f;
+    const int slot = q0 + wave * FA_WQ + qt * 16 + lq;
+    const bool ok = slot < L;
     // delta = rowsum(O o dO) of this query is computed HERE (the dO fragment is loaded anyway) and published for the
     // dK/dV kernel, which runs after this one: no separate delta pass over O and dO
     float dsum = 0.f;
 #pragma unroll
     for (int ks = 0; ks < A::NKS; ++ks) {
-      int d0 = 32 * ks + 8 * g;
-      uint4 v = make_uint4(0, 0, 0, 0), u = make_uint4(0, 0, 0, 0), o = make_uint4(0, 0, 0, 0);
-      if (row >= 0 && d0 < D) v = ld16(qkv + row * C3 + h * D + d0);
-      if (srow[qt] >= 0 && d0 < D) { u = ld16(dout + (int64_t)srow[qt] * C + h * D + d0); o = ld16(outp + (int64_t)srow[qt] * C + h * D + d0); }
+      const uint4 v = qv[qt][ks], u = gv[qt][ks], o = ov[qt][ks];
       qf[qt][ks] = as_bf8(PAD ? scale_bf16x8(v, c2) : v); gf[qt][ks] = as_bf8(u);
       const unsigned int* uu = reinterpret_cast<const unsigned int*>(&u);
       const unsigned int* uo = reinterpret_cast<const unsigned int*>(&o);
@@ -436,7 +483,6 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
   for (int qt = 0; qt < FA_NT; ++qt)
 #pragma unroll
     for (int dt = 0; dt < A::NDT; ++dt) dq[dt][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  uint4 stA[NLD], stB[NLD];
   auto stage_write = [&](uint4 (&stage)[NLD], int b) {
     char* base = smem + b * BUF;
 #pragma unroll
@@ -454,15 +500,14 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
     }
   };
   const int ntiles = (L + FA_BK - 1) / FA_BK;
-  tile_load<D, NLD>(stA, qkv, gidx_s, 0, L, C3, C + h * D, 2 * C + h * D, tid);
-  stage_write(stA, 0);
+  stage_write(stA, 0);                         // tile 0 was fetched in round 2 of the prologue
   if (FA_PREFETCH2 && ntiles > 1) tile_load<D, NLD>(stA, qkv, gidx_s, FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
   if (FA_PREFETCH2 && ntiles > 2) tile_load<D, NLD>(stB, qkv, gidx_s, 2 * FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
   __syncthreads();
   auto step = [&](const int t, uint4 (&stage)[NLD]) {        // FA_PREFETCH2: stage holds tile t+1
     const int b = t & 1, kv0 = t * FA_BK;
     const char* Kr = smem + b * BUF; const char* Vr = Kr + RIMG; const char* Kt = Kr + 2 * RIMG;
-    if (!FA_PREFETCH2 && t + 1 < ntiles) tile_load<D, NLD>(stage, qkv, gidx_s, kv0 + FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
+    if (!FA_PREFETCH2 && t + 1 < ntiles && !(FA_ABL & 1)) tile_load<D, NLD>(stage, qkv, gidx_s, kv0 + FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
     f32x4_t s[4][FA_NT], dp[4][FA_NT];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -505,7 +550,7 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
         for (int qt = 0; qt < FA_NT; ++qt) dq[dt][qt] = MFMA16(kf, df[qt], dq[dt][qt]);
       }
     }
-    if (t + 1 < ntiles) stage_write(stage, b ^ 1);
+    if (t + 1 < ntiles && !(FA_ABL & 1)) stage_write(stage, b ^ 1);
     if (FA_PREFETCH2 && t + 3 < ntiles) tile_load<D, NLD>(stage, qkv, gidx_s, kv0 + 3 * FA_BK, L, C3, C + h * D, 2 * C + h * D, tid);
     __syncthreads();
   };
@@ -519,7 +564,7 @@ k_attn_bwd_dq_mfma(const unsigned short* __restrict__ qkv, const unsigned short*
   }
 #pragma unroll
   for (int qt = 0; qt < FA_NT; ++qt) {
-    if (srow[qt] >= 0) {
+    if (srow[qt] >= 0 && !(FA_ABL & 64)) {
       unsigned short* op = dqkv + (int64_t)srow[qt] * C3 + h * D + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < A::NDT; ++dt) {
@@ -565,14 +610,75 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
   const int p0 = win_start[w], L = win_start[w + 1] - p0;
   const int k0 = kc * DKV_BKEYS;
   if (k0 >= L) return;
-  for (int i = tid; i < L; i += DKV_THREADS) {          // offsets in 16-byte units (row * 3C/8, row * C/8); borrowed slots stay < 0
-    gidx_s[i] = (int32_t)((uint32_t)gidx[p0 + i] * (uint32_t)(3 * C >> 3));
-    int32_t sr = sidx[p0 + i];
-    sidx_s[i] = sr >= 0 ? sr * (C >> 3) : -1;
-  }
-  __syncthreads();
+  // ---- prologue in TWO dependent rounds of global loads (was four: index copies | barrier | key indices | K / V rows,
+  // first Q / dO tile): round 1 = everything addressed by p0 alone, round 2 = the rows those indices name
   const int64_t C3 = 3 * (int64_t)C;
   const float c2 = scale * 1.44269504088896340736f;
+  constexpr bool PAD = A::CHP > A::CH;
+  constexpr int PADKS = D / 32, PADG = (D % 32) / 8;
+  constexpr int NFILL = FA_IDX_CAP / DKV_THREADS;
+  int32_t fillg[NFILL], fills[NFILL];
+#pragma unroll
+  for (int k = 0; k < NFILL; ++k) {
+    const int i = tid + k * DKV_THREADS;
+    fillg[k] = i < L ? gidx[p0 + i] : 0; fills[k] = i < L ? sidx[p0 + i] : -1;
+  }
+  int kslot[FA_NT];
+  int32_t ksr[FA_NT];
+  int64_t krow[FA_NT];
+#pragma unroll
+  for (int kt = 0; kt < FA_NT; ++kt) {
+    kslot[kt] = k0 + wave * FA_WQ + kt * 16 + lq;
+    krow[kt] = kslot[kt] < L ? gidx[p0 + kslot[kt]] : -1;
+    ksr[kt] = kslot[kt] < L ? sidx[p0 + kslot[kt]] : -1;      // destination row of the key (read in the epilogue): fetched now
+  }
+  struct Stage { uint4 v[NLD]; float l, d; };
+  Stage stA, stB;
+  stA.l = stA.d = stB.l = stB.d = 0.f;
+  int32_t s0idx[NLD];                       // first (Q, dO) tile: row index of this thread's chunks (Q: gather row, dO: scatter row)
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int c = i * DKV_THREADS + tid;
+    const int second = c >= FA_BQ2 * A::CH;
+    const int r = (second ? c - FA_BQ2 * A::CH : c) / A::CH;
+    s0idx[i] = (c < TOT && r < L) ? (second ? sidx[p0 + r] : gidx[p0 + r]) : -1;
+  }
+  if (tid < FA_BQ2) {
+    const bool ok = tid < L;
+    stA.l = ok ? lse[(int64_t)(p0 + tid) * H + h] * 1.44269504088896340736f : 1e30f;   // p = 0 for rows past the window
+    stA.d = ok ? delta[(int64_t)(p0 + tid) * H + h] : 0.f;
+  }
+  // round 2
+  uint4 ka[FA_NT][A::NKS], vb[FA_NT][A::NKS];
+#pragma unroll
+  for (int kt = 0; kt < FA_NT; ++kt)
+#pragma unroll
+    for (int ks = 0; ks < A::NKS; ++ks) {
+      const int d0 = 32 * ks + 8 * g;
+      ka[kt][ks] = vb[kt][ks] = make_uint4(0, 0, 0, 0);
+      if (krow[kt] >= 0 && d0 < D && !(FA_ABL & 128)) {
+        ka[kt][ks] = ld16(qkv + krow[kt] * C3 + C + h * D + d0); vb[kt][ks] = ld16(qkv + krow[kt] * C3 + 2 * C + h * D + d0);
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int c = i * DKV_THREADS + tid;
+    const int second = c >= FA_BQ2 * A::CH;
+    const int cc = second ? c - FA_BQ2 * A::CH : c;
+    const int ch = cc - (cc / A::CH) * A::CH;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (s0idx[i] >= 0) {
+      if (!second) v = ld16(qkv + (int64_t)s0idx[i] * C3 + h * D + ch * 8);
+      else v = ld16(dout + (int64_t)s0idx[i] * C + h * D + ch * 8);
+    }
+    stA.v[i] = v;
+  }
+  // LDS: row offsets in 16-byte units (row * 3C/8, row * C/8; borrowed slots stay < 0), contraction padding
+#pragma unroll
+  for (int k = 0; k < NFILL; ++k) {
+    const int i = tid + k * DKV_THREADS;
+    if (i < L) { gidx_s[i] = (int32_t)((uint32_t)fillg[k] * (uint32_t)(3 * C >> 3)); sidx_s[i] = fills[k] >= 0 ? fills[k] * (C >> 3) : -1; }
+  }
   if (A::CHP > A::CH) {
     for (int e = tid; e < 4 * FA_BQ2 * (A::CHP - A::CH); e += DKV_THREADS) {
       int img = e / (FA_BQ2 * (A::CHP - A::CH)); int r = (e / (A::CHP - A::CH)) % FA_BQ2; int ch = A::CH + e % (A::CHP - A::CH);
@@ -580,21 +686,14 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
       *reinterpret_cast<uint4*>(base + row_img_off<D>(r, ch)) = make_uint4(0, 0, 0, 0);
     }
   }
-  constexpr bool PAD = A::CHP > A::CH;
-  constexpr int PADKS = D / 32, PADG = (D % 32) / 8;
+  __syncthreads();
   // K / V fragments as B operands: lane holds K[key = lq][d = 32ks + 8g ..]
   bf8_t kf[FA_NT][A::NKS], vf[FA_NT][A::NKS];
-  int kslot[FA_NT];
 #pragma unroll
-  for (int kt = 0; kt < FA_NT; ++kt) {
-    int slot = k0 + wave * FA_WQ + kt * 16 + lq;
-    kslot[kt] = slot;
-    int64_t row = slot < L ? gidx[p0 + slot] : -1;
+  for (int kt = 0; kt < FA_NT; ++kt)
 #pragma unroll
     for (int ks = 0; ks < A::NKS; ++ks) {
-      int d0 = 32 * ks + 8 * g;
-      uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, 0);
-      if (row >= 0 && d0 < D) { a = ld16(qkv + row * C3 + C + h * D + d0); b = ld16(qkv + row * C3 + 2 * C + h * D + d0); }
+      uint4 a = ka[kt][ks], b = vb[kt][ks];
       if (PAD) {
         // K pre-scaled by scale*log2(e); contraction columns D, D+1 of both fragments carry 1, 1: the streamed Q / dO rows
         // hold -(lse2) / -(delta) there as bf16 hi + lo, so the MFMAs deliver c2*S - lse2 and dP - delta directly
@@ -603,7 +702,6 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
       }
       kf[kt][ks] = as_bf8(a); vf[kt][ks] = as_bf8(b);
     }
-  }
   f32x4_t dk[A::NDT][FA_NT], dv[A::NDT][FA_NT];
 #pragma unroll
   for (int kt = 0; kt < FA_NT; ++kt)
@@ -611,9 +709,6 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
     for (int dt = 0; dt < A::NDT; ++dt) { dk[dt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   // two register stages (tile written at the bottom of step t was requested two steps earlier): a 32-query step
   // is ~28 MFMAs per wave, far shorter than a gathered-row fetch, and only 2 workgroups fit a CU
-  struct Stage { uint4 v[NLD]; float l, d; };
-  Stage stA, stB;
-  stA.l = stA.d = stB.l = stB.d = 0.f;
   auto stage_load = [&](Stage& st, int qb) {
     uint4 (&stage)[NLD] = st.v; float& st_l = st.l; float& st_d = st.d;
 #pragma unroll
@@ -662,14 +757,13 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
     }
   };
   const int ntiles = (L + FA_BQ2 - 1) / FA_BQ2;
-  stage_load(stA, 0);
-  stage_write(stA, 0);
+  stage_write(stA, 0);                         // the first tile was fetched in round 2 of the prologue
   if (FA_PREFETCH2 && ntiles > 1) stage_load(stA, FA_BQ2);
   if (FA_PREFETCH2 && ntiles > 2) stage_load(stB, 2 * FA_BQ2);
   __syncthreads();
   auto step = [&](const int t, Stage& st) {                  // FA_PREFETCH2: st holds tile t+1
     const int b = t & 1;
-    if (!FA_PREFETCH2 && t + 1 < ntiles) stage_load(st, (t + 1) * FA_BQ2);
+    if (!FA_PREFETCH2 && t + 1 < ntiles && !(FA_ABL & 1)) stage_load(st, (t + 1) * FA_BQ2);
     const char* Qr = smem + b * BUF; const char* Gr = Qr + RIMG; const char* Qt = Qr + 2 * RIMG; const char* Gt = Qt + TIMG;
     const float* fl = reinterpret_cast<const float*>(Qr + 2 * RIMG + 2 * TIMG);
 #pragma unroll
@@ -724,7 +818,7 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
       }
     }
     }   // hq
-    if (t + 1 < ntiles) stage_write(st, b ^ 1);
+    if (t + 1 < ntiles && !(FA_ABL & 1)) stage_write(st, b ^ 1);
     if (FA_PREFETCH2 && t + 3 < ntiles) stage_load(st, (t + 3) * FA_BQ2);
     __syncthreads();
   };
@@ -739,8 +833,8 @@ k_attn_bwd_dkv_mfma(const unsigned short* __restrict__ qkv, const unsigned short
 #pragma unroll
   for (int kt = 0; kt < FA_NT; ++kt) {
     int slot = kslot[kt];
-    if (slot < L) {
-      int32_t sr = sidx[p0 + slot];
+    if (slot < L && !(FA_ABL & 64)) {
+      int32_t sr = ksr[kt];
       unsigned short* kp; unsigned short* vp;
       if (sr >= 0) { kp = dqkv + (int64_t)sr * C3 + C + h * D + 4 * g; vp = kp + C; }
       else { kp = extra + (int64_t)(-1 - sr) * 2 * C + h * D + 4 * g; vp = kp + C; }

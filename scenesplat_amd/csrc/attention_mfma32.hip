@@ -163,16 +163,27 @@ k_attn_fwd_mfma32(const unsigned short* __restrict__ qkv, const int32_t* __restr
   // ---- Q fragments (B operand of S^T = K Q^T): lane (query lr, half hh) of q-block qb holds Q[q][16 ks + 8 hh .. +7]
   bf8_t qf[FA32_NQB][A::NKS];
   int qslot[FA32_NQB];
+  int32_t srow_[FA32_NQB];            // destination row of the query, fetched now: a load in the epilogue would be a full
+                                      // memory round trip at the end of every workgroup
 #pragma unroll
   for (int qb = 0; qb < FA32_NQB; ++qb) {
     qslot[qb] = q0 + wave * FA32_WQ + 32 * qb + lr;
     const int64_t row = qslot[qb] < L ? gidx[p0 + qslot[qb]] : -1;
+    srow_[qb] = qslot[qb] < L ? sidx[p0 + qslot[qb]] : -1;
 #pragma unroll
     for (int ks = 0; ks < A::NKS; ++ks) {
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (row >= 0) v = *reinterpret_cast<const uint4*>(qkv + row * C3 + h * D + 16 * ks + 8 * hh);
+      if (row >= 0 && !(FA32_ABL & 128)) v = *reinterpret_cast<const uint4*>(qkv + row * C3 + h * D + 16 * ks + 8 * hh);
+      else if (FA32_ABL & 128) v = make_uint4(0x3c003c00u + lane, 0x3c003c00u, 0x3c003c00u + ks, 0x3c003c00u);
       qf[qb][ks] = as_bf8_(v);
     }
+  }
+  // first K / V tile: its row indices come straight from global memory in the same round as the query indices, its rows in
+  // the same round as the Q rows -- the prologue is two dependent memory round trips, not three
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const uint64_t o16 = (uint32_t)gidx[p0 + min(st_row[i], L - 1)] * (uint32_t)(3 * C >> 3);
+    stg[i] = *reinterpret_cast<const u32x4_t*>(st_src[i] + (o16 << 4));
   }
   f32x16_t o[FA32_NQB][A::NMT];
   float m2[FA32_NQB], lsum[FA32_NQB];     // shift in exp2 units (scale * log2e * score); lsum only without a spare row
@@ -300,7 +311,6 @@ k_attn_fwd_mfma32(const unsigned short* __restrict__ qkv, const int32_t* __restr
   __syncthreads();                   // gidx_s ready
 #if FA32_PIPE
   // prologue: K(0), V(0) -> images 0; K(1) -> K image 1 (V(0) is simply written twice); S(0) and its maximum
-  fa32_tile_load<NLD>(stg, gidx_s, 0, 0, st_row, st_isv, st_src);
   fa32_tile_write<NLD>(stg, Kimg(0), Vimg(0), st_isv, st_lds);
   fa32_tile_load<NLD>(stg, gidx_s, ntiles > 1 ? FA32_BK : 0, 0, st_row, st_isv, st_src);
   __syncthreads();
@@ -333,8 +343,7 @@ k_attn_fwd_mfma32(const unsigned short* __restrict__ qkv, const int32_t* __restr
   }
 #else
   // plain loop: tile t+1 is loaded into registers at the top and written to the other image pair at the bottom
-  fa32_tile_load<NLD>(stg, gidx_s, 0, 0, st_row, st_isv, st_src);
-  fa32_tile_write<NLD>(stg, Kimg(0), Vimg(0), st_isv, st_lds);
+  fa32_tile_write<NLD>(stg, Kimg(0), Vimg(0), st_isv, st_lds);      // tile 0 was fetched beside the Q rows
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int b = t & 1;
@@ -362,22 +371,34 @@ k_attn_fwd_mfma32(const unsigned short* __restrict__ qkv, const int32_t* __restr
     }
     if (qslot[qb] < L) {
       if (hh == 0) lse[(int64_t)(p0 + qslot[qb]) * H + h] = m2[qb] * 0.69314718055994530942f + __logf(lt);
-      const int32_t srow = sidx[p0 + qslot[qb]];
-      if (srow >= 0) {
+      const int32_t srow = srow_[qb];
+      if (srow >= 0 && !(FA32_ABL & 64)) {
+        // Lane (q, hh) holds columns 8 g4 + 4 hh .. +3 of its row for every 8-column group g4: 8-byte pieces.  Pairs of
+        // groups are exchanged between the two half-waves (v_permlane32_swap) so that every lane owns 16 contiguous bytes:
+        // hh = 0 gets columns 16 j .. 16 j + 7, hh = 1 columns 16 j + 8 .. + 15 -- half the store instructions (the row
+        // pieces are scattered by row, the tail is store-issue-bound: -0.09 ms of 0.54 at dec0 with the stores removed)
         const float inv = 1.f / lt;
-        unsigned short* op = out + (int64_t)srow * C + h * D + 4 * hh;
+        unsigned short* op = out + (int64_t)srow * C + h * D + 8 * hh;
+        constexpr int NG = D / 8;                                  // 8-column groups that hold real columns
 #pragma unroll
-        for (int mt = 0; mt < A::NMT; ++mt)
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const int d0 = 32 * mt + 8 * g4;
-            if (d0 < D) {
-              uint2 v;
-              v.x = pack_bf16x2(o[qb][mt][4 * g4 + 0] * inv, o[qb][mt][4 * g4 + 1] * inv);
-              v.y = pack_bf16x2(o[qb][mt][4 * g4 + 2] * inv, o[qb][mt][4 * g4 + 3] * inv);
-              *reinterpret_cast<uint2*>(op + d0) = v;
-            }
+        for (int j = 0; j < (NG + 1) / 2; ++j) {
+          const int ga = 2 * j, gb = 2 * j + 1;                    // group index = 4 mt + g4
+          uint2 a, b;
+          a.x = pack_bf16x2(o[qb][ga >> 2][4 * (ga & 3) + 0] * inv, o[qb][ga >> 2][4 * (ga & 3) + 1] * inv);
+          a.y = pack_bf16x2(o[qb][ga >> 2][4 * (ga & 3) + 2] * inv, o[qb][ga >> 2][4 * (ga & 3) + 3] * inv);
+          if (gb < NG) {
+            b.x = pack_bf16x2(o[qb][gb >> 2][4 * (gb & 3) + 0] * inv, o[qb][gb >> 2][4 * (gb & 3) + 1] * inv);
+            b.y = pack_bf16x2(o[qb][gb >> 2][4 * (gb & 3) + 2] * inv, o[qb][gb >> 2][4 * (gb & 3) + 3] * inv);
+            // swap: upper half of a <-> lower half of b; afterwards (a.x, a.y, b.x, b.y) are 16 contiguous bytes in both halves
+            auto rx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+            auto ry = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+            // lanes < 32: own group ga (cols +0..3) then the upper half's group ga (cols +4..7); lanes >= 32: the lower
+            // half's group gb (cols +8..11) then own group gb (cols +12..15)
+            *reinterpret_cast<uint4*>(op + 16 * j) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+          } else {
+            *reinterpret_cast<uint2*>(out + (int64_t)srow * C + h * D + 8 * ga + 4 * hh) = a;      // odd group count (d = 8 mod 16)
           }
+        }
       }
     }
   }
