@@ -128,6 +128,12 @@ int ss_subm_conv_wgrad_pipe(const void* in, const void* dout, const int32_t* nbr
                             int taps, ss_stream_t stream);
 int ss_linear_wgrad(const void* x, const void* dy, float* dweight, float* dbias, int64_t m, int k_in, int n_out,
                     ss_stream_t stream);
+/* Grouped form: ONE launch for up to 128 independent nn.Linear weight gradients (the blocks of a pooled stage).
+ * desc (nprob, 8) int64 in device memory, per problem {x, dy, dweight, dbias | 0, m, and three words filled by
+ * ss_linear_wgrad_group_plan}; wg_start (nprob + 1) int32 device = running total of the workgroup counts that
+ * ss_linear_wgrad_group_plan returns (host call, no launch; 0 = shape not eligible); every dweight / dbias zeroed. */
+int ss_linear_wgrad_group_plan(int64_t m, int k_in, int n_out, int64_t* desc_words);
+int ss_linear_wgrad_group(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups, ss_stream_t stream);
 /* small levels: split-K over tap ranges; acc32 (n,cout) f32 zeroed by the caller, receives out (+bias) */
 int ss_subm_conv_splits(int64_t n, int cout, int taps);
 int ss_subm_conv_fwd_splitk(const void* in, const void* weight, const float* bias, const int32_t* nbr, const int32_t* rowperm,

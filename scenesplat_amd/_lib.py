@@ -54,6 +54,8 @@ PROTOTYPES = {
     "ss_wgrad8_ok": (c_i, [c_i64, c_i, c_i, c_i]),
     "ss_subm_conv_wgrad_pipe": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "ss_linear_wgrad": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p]),
+    "ss_linear_wgrad_group_plan": (c_i, [c_i64, c_i, c_i, c_p]),
+    "ss_linear_wgrad_group": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "ss_subm_conv_splits": (c_i, [c_i64, c_i, c_i]),
     "ss_subm_conv_fwd_splitk": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "ss_subm_block_lists": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p]),

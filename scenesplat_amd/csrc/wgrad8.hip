@@ -49,12 +49,14 @@ __device__ __forceinline__ w8_bf8_t w8_tr2(const char* p) {       // k rows r0 a
   return __builtin_bit_cast(w8_bf8_t, v);
 }
 
+// The whole workgroup program; L = the workgroup's id inside its problem (a plain launch passes blockIdx.x, the grouped
+// launch blockIdx.x minus the problem's first workgroup).
 template <bool GATHER>
-__global__ void __launch_bounds__(512)
-k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY, const int32_t* __restrict__ nbr,
-         const int32_t* __restrict__ rowperm, const int32_t* __restrict__ blk_count, const int32_t* __restrict__ blk_list,
-         float* __restrict__ dW, float* __restrict__ dbias, int n, int Cin, int Cout, int taps, int ntn, int nblocks_total,
-         int min_per, int ntiles, int nshares) {
+__device__ __forceinline__ void
+w8_body(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY, const int32_t* __restrict__ nbr,
+        const int32_t* __restrict__ rowperm, const int32_t* __restrict__ blk_count, const int32_t* __restrict__ blk_list,
+        float* __restrict__ dW, float* __restrict__ dbias, int n, int Cin, int Cout, int taps, int ntn, int nblocks_total,
+        int min_per, int ntiles, int nshares, const int L) {
   __shared__ __attribute__((aligned(16))) char smem[GATHER ? W8_LDS_BYTES : 2 * W8_BUF];
   int32_t* isite_s = reinterpret_cast<int32_t*>(smem + W8_OFF_ISITE);
   int32_t* jsite_s = reinterpret_cast<int32_t*>(smem + W8_OFF_JSITE);
@@ -63,7 +65,6 @@ k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict_
   // ids in (share, tap, tile) order, tile fastest: the tiles of one (tap, share) -- which stream the SAME site rows -- are
   // dealt round-robin over the XCDs.  Measured: giving them to ONE XCD (to share its L2) is 20-45 % SLOWER (768 -> 768
   // Linear 191 -> 232 us, conv dec0 1.20 -> 1.64 ms): eight L2s and the Infinity Cache serve the re-reads better than one.
-  const int L = blockIdx.x;
   const int tile = L % ntiles, group = L / ntiles;                             // group = share * taps + tap
   const int tap = group % taps, share = group / taps;
   const int m0 = (tile / ntn) * 256, n0 = (tile % ntn) * 256;                  // Cout, Cin origins
@@ -284,6 +285,36 @@ k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict_
 }
 
 #undef W8_BIAS
+
+template <bool GATHER>
+__global__ void __launch_bounds__(512)
+k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY, const int32_t* __restrict__ nbr,
+         const int32_t* __restrict__ rowperm, const int32_t* __restrict__ blk_count, const int32_t* __restrict__ blk_list,
+         float* __restrict__ dW, float* __restrict__ dbias, int n, int Cin, int Cout, int taps, int ntn, int nblocks_total,
+         int min_per, int ntiles, int nshares) {
+  w8_body<GATHER>(X, DY, nbr, rowperm, blk_count, blk_list, dW, dbias, n, Cin, Cout, taps, ntn, nblocks_total, min_per, ntiles,
+                  nshares, (int)blockIdx.x);
+}
+
+// Grouped nn.Linear weight gradients: ONE launch for many independent problems (the six identical blocks of a pooled
+// stage produce thirty weight gradients of 20-30 us each, latency-bound on 12-20 workgroups apiece).  desc: 8 int64 words
+// per problem = {x, dy, dW, dbias, m, k_in | n_out << 32, ntn | ntiles << 32, nshares | min_per << 32}; wg_start
+// (nprob + 1): first workgroup of every problem.
+__global__ void __launch_bounds__(512)
+k_wgrad8_group(const int64_t* __restrict__ desc, const int32_t* __restrict__ wg_start, int nprob) {
+  const int b = blockIdx.x;
+  int p = 0;
+  while (p + 1 < nprob && wg_start[p + 1] <= b) ++p;          // nprob <= 128: a scalar scan
+  const int64_t* d = desc + (int64_t)p * 8;
+  const int64_t m = d[4];
+  const uint64_t w5 = (uint64_t)d[5], w6 = (uint64_t)d[6], w7 = (uint64_t)d[7];
+  const int k_in = (int)(w5 & 0xffffffffu), n_out = (int)(w5 >> 32);
+  const int ntn = (int)(w6 & 0xffffffffu), ntiles = (int)(w6 >> 32);
+  const int nshares = (int)(w7 & 0xffffffffu), min_per = (int)(w7 >> 32);
+  w8_body<false>((const unsigned short*)d[0], (const unsigned short*)d[1], nullptr, nullptr, nullptr, nullptr, (float*)d[2],
+                 (float*)d[3], (int)m, k_in, n_out, 1, ntn, (int)((m + 63) / 64), min_per, ntiles, nshares, b - wg_start[p]);
+}
+
 extern "C" int ss_wgrad8_ok(int64_t n, int cin, int cout, int taps) {
   return n > 0 && n < (1LL << 31) && cin >= 8 && (cin & 7) == 0 && cin <= W8_ZERO_ELEMS && cout >= 8 && (cout & 7) == 0 &&
          cout <= W8_ZERO_ELEMS && taps >= 1;
@@ -317,20 +348,48 @@ extern "C" int ss_subm_conv_wgrad_pipe(const void* in, const void* dout, const i
   return SS_OK;
 }
 
+// share sizing of one nn.Linear weight gradient: every block is active here, so the shares are exact: one round of
+// <= 256 workgroups (one per CU), shares of at least 8 K-tiles (270 workgroups on 256 CUs ran two rounds: qkv 768->2304
+// took 622 us, 243 workgroups 440 us)
+static void w8_linear_plan(int64_t m, int k_in, int n_out, int* tm_, int* tn_, int* min_per_, int* splits_) {
+  const int nblocks = ss_div_up(m, 64);
+  const int tm = ss_div_up(n_out, 256), tn = ss_div_up(k_in, 256);
+  static int env_per = -2;
+  if (env_per == -2) { const char* e = getenv("SS_WGRAD_MINPER"); env_per = e ? atoi(e) : -1; }
+  int min_per = env_per > 0 ? env_per : (int)(((int64_t)nblocks * tm * tn + 255) / 256);
+  if (env_per <= 0 && min_per < 8) min_per = 8;
+  if (min_per > nblocks) min_per = nblocks;
+  *tm_ = tm; *tn_ = tn; *min_per_ = min_per; *splits_ = ss_div_up(nblocks, min_per);
+}
+
+// Host half of the grouped launch: fills desc words 5..7 of one problem (words 0..4 = x, dy, dW, dbias, m are the
+// caller's) and returns the number of workgroups the problem takes (0 = not eligible).
+extern "C" int ss_linear_wgrad_group_plan(int64_t m, int k_in, int n_out, int64_t* desc_words) {
+  if (m <= 0 || !ss_wgrad8_ok(m, k_in, n_out, 1) || !desc_words) return 0;
+  int tm, tn, min_per, splits;
+  w8_linear_plan(m, k_in, n_out, &tm, &tn, &min_per, &splits);
+  desc_words[5] = (int64_t)((uint64_t)(uint32_t)k_in | ((uint64_t)(uint32_t)n_out << 32));
+  desc_words[6] = (int64_t)((uint64_t)(uint32_t)tn | ((uint64_t)(uint32_t)(tm * tn) << 32));
+  desc_words[7] = (int64_t)((uint64_t)(uint32_t)splits | ((uint64_t)(uint32_t)min_per << 32));
+  return splits * tm * tn;
+}
+
+// desc (nprob, 8) int64 and wg_start (nprob + 1) int32 in DEVICE memory (see k_wgrad8_group); every dW / dbias zeroed.
+extern "C" int ss_linear_wgrad_group(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups,
+                                     hipStream_t stream) {
+  if (nprob <= 0 || total_workgroups <= 0) return SS_OK;
+  if (!desc || !wg_start || nprob > 128) return SS_ERR_ARG;
+  SS_LAUNCH(k_wgrad8_group, dim3((unsigned)total_workgroups), dim3(512), 0, stream, desc, wg_start, nprob);
+  return SS_OK;
+}
+
 extern "C" int ss_linear_wgrad(const void* x, const void* dy, float* dweight, float* dbias, int64_t m, int k_in, int n_out,
                                hipStream_t stream) {
   if (m == 0) return SS_OK;
   if (!ss_wgrad8_ok(m, k_in, n_out, 1)) return SS_ERR_ARG;
   const int nblocks = ss_div_up(m, 64);
-  const int tm = ss_div_up(n_out, 256), tn = ss_div_up(k_in, 256);
-  static int env_per = -2;
-  if (env_per == -2) { const char* e = getenv("SS_WGRAD_MINPER"); env_per = e ? atoi(e) : -1; }
-  // every block is active here, so the shares are exact: one round of <= 256 workgroups (one per CU), shares of at
-  // least 8 K-tiles (270 workgroups on 256 CUs ran two rounds: qkv 768->2304 took 622 us, 243 workgroups 440 us)
-  int min_per = env_per > 0 ? env_per : (int)(((int64_t)nblocks * tm * tn + 255) / 256);
-  if (env_per <= 0 && min_per < 8) min_per = 8;
-  if (min_per > nblocks) min_per = nblocks;
-  int splits = ss_div_up(nblocks, min_per);
+  int tm, tn, min_per, splits;
+  w8_linear_plan(m, k_in, n_out, &tm, &tn, &min_per, &splits);
   dim3 g((unsigned)(splits * tm * tn));
   SS_LAUNCH((k_wgrad8<false>), g, dim3(512), 0, stream, (const unsigned short*)x, (const unsigned short*)dy,
             (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, dweight,

@@ -508,17 +508,69 @@ def defer_marker(x):
     return _DeferMarker.apply(x) if (_Defer.enabled and x.requires_grad) else x
 
 
+# ---- grouped weight gradients of a stage ------------------------------------------------------------------------------
+# On the pooled levels a Linear weight gradient is a 20-30 us, latency-bound launch on 12-20 workgroups, and a stage has
+# 5 per block (86 such launches = 2.7 ms per step).  They do not feed the backward chain, so the blocks of a stage QUEUE
+# them and ONE grouped launch (ss_linear_wgrad_group) computes them when the chain leaves the stage.  DDP-safe by
+# construction: the stage's parameters enter the stage through an identity node (_StageParams) whose backward runs after
+# every consumer inside the stage has returned -- it launches the group and only then hands the (already returned,
+# zero-initialised, stream-ordered) gradient buffers on to AccumulateGrad and the bucket hooks.
+WGRAD_GROUP_MAX_ROWS = int(os.environ.get("SS_WGRAD_GROUP_MAX", "32768"))    # 0 disables grouping
+_STAGE = {"cur": None, "route": {}}
+
+
+class _WgradStage:
+    def __init__(self):
+        self.queue = []
+
+    def flush(self):
+        q, self.queue = self.queue, []
+        nv.linear_wgrad_group(q)
+
+
+class _StageParams(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, stage, *params):
+        ctx.stage = stage
+        ctx.set_materialize_grads(False)
+        return tuple(p.view_as(p) for p in params)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ctx.stage.flush()
+        return (None,) + grads
+
+
+def stage_begin(linears, n_rows):
+    """Route the parameters of a stage's nn.Linear modules through one identity node (training under bf16 autocast only)."""
+    _STAGE["cur"], _STAGE["route"] = None, {}
+    if not (WGRAD_GROUP_MAX_ROWS and LINEAR_WGRAD_MIN_ROWS <= n_rows <= WGRAD_GROUP_MAX_ROWS and torch.is_grad_enabled()
+            and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+        return
+    params = [p for m in linears for p in (m.weight, m.bias) if p is not None and p.requires_grad and p.dtype == torch.float32 and p.is_cuda]
+    if not params:
+        return
+    stage = _WgradStage()
+    aliases = _StageParams.apply(stage, *params)
+    _STAGE["cur"], _STAGE["route"] = stage, {id(p): a for p, a in zip(params, aliases)}
+
+
+def stage_end():
+    _STAGE["cur"], _STAGE["route"] = None, {}
+
+
 class _Linear(torch.autograd.Function):
     """nn.Linear under bf16 autocast.  Forward and dgrad stay on hipBLASLt (NT / NN forms run at 0.9-1.3 PFLOP/s
     there); the weight gradient dy^T x -- K = sites, 0.25-0.7 PFLOP/s in hipBLASLt's TN form -- runs on the
-    LDS-DMA pipeline kernel (csrc/wgrad8.hip) and lands in fp32 directly, without the bf16 -> fp32 grad cast."""
+    LDS-DMA pipeline kernel (csrc/wgrad8.hip) and lands in fp32 directly, without the bf16 -> fp32 grad cast.
+    weight / bias are the parameters or their stage aliases (gradient routing only); w16 / b16 the bf16 operands."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        w16 = bf16_of(weight)
-        y = torch.nn.functional.linear(x, w16, bf16_of(bias))
+    def forward(ctx, x, weight, bias, w16, b16, stage):
+        y = torch.nn.functional.linear(x, w16, b16)
         ctx.save_for_backward(x, w16)
         ctx.meta = (weight.dtype, bias is not None)
+        ctx.stage = stage
         return y
 
     @staticmethod
@@ -533,7 +585,13 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             m, k = x.shape
             if m >= LINEAR_WGRAD_MIN_ROWS and nv.lib().ss_wgrad8_ok(m, k, dy.shape[1], 1):
-                if _Defer.open and w_dtype == torch.float32:
+                if ctx.stage is not None and w_dtype == torch.float32:
+                    # queued: the stage's identity node launches the whole group when the backward chain leaves the stage
+                    dw, db_ = nv.linear_wgrad_alloc(k, dy.shape[1], want_db, x.device)
+                    ctx.stage.queue.append((x, dy, dw, db_))
+                    if want_db:
+                        db, want_db = db_, False
+                elif _Defer.open and w_dtype == torch.float32:
                     dw, db_ = nv.linear_wgrad_alloc(k, dy.shape[1], want_db, x.device)
                     _defer(lambda: nv.linear_wgrad_into(x, dy, dw, db_), (x, dy, dw))
                     if want_db:
@@ -548,7 +606,7 @@ class _Linear(torch.autograd.Function):
                 dw = _mm_f32(dy.t(), x).to(w_dtype)     # small levels: library GEMM, fp32 out where aten::mm.dtype exists
         if want_db:
             db = dy.sum(0, dtype=torch.float32).to(w_dtype)
-        return dx, dw, db
+        return dx, dw, db, None, None, None
 
 
 LINEAR_WGRAD_MIN_ROWS = 1024     # in-process A/B on room-102400: 1024 beats 4096 by 0.5 ms/step
@@ -558,7 +616,13 @@ def linear(x, weight, bias=None):
     """torch.nn.functional.linear; under CUDA bf16 autocast on 2-D input the backward uses the pipeline wgrad kernel."""
     if x.is_cuda and x.dim() == 2 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16 \
             and weight.dtype == torch.float32:
-        return _Linear.apply(x.to(torch.bfloat16).contiguous(), weight, bias)
+        route = _STAGE["route"]
+        wr = route.get(id(weight)) if route else None
+        if wr is not None and torch.is_grad_enabled():
+            br = route.get(id(bias)) if bias is not None else None
+            return _Linear.apply(x.to(torch.bfloat16).contiguous(), wr, br if br is not None else bias, bf16_of(weight), bf16_of(bias),
+                                 _STAGE["cur"])
+        return _Linear.apply(x.to(torch.bfloat16).contiguous(), weight, bias, bf16_of(weight), bf16_of(bias), None)
     return torch.nn.functional.linear(x, weight, bias)
 
 

@@ -312,6 +312,44 @@ def linear_wgrad_into(x, dy, dw, db):
     check(lib().ss_linear_wgrad(_p(x), _p(dy), _p(dw), _p(db), m, k, nout, _stream()), "ss_linear_wgrad")
 
 
+_GROUP_KEEP = []      # descriptor tensors of the last grouped launches (kept alive until the copies have certainly run)
+
+
+def linear_wgrad_group(items):
+    """ONE launch for many nn.Linear weight gradients.  items: list of (x (m,k) bf16, dy (m,n) bf16, dw (n,k) f32 ZEROED,
+    db (n) f32 ZEROED | None).  Problems the pipeline kernel cannot take are run one by one."""
+    import numpy as np
+    if not items:
+        return
+    dev = items[0][0].device
+    desc = np.zeros((len(items), 8), dtype=np.int64)
+    starts = [0]
+    rows = []
+    for x, dy, dw, db in items:
+        _req(x, torch.bfloat16, "x"); _req(dy, torch.bfloat16, "dy", (x.shape[0], dy.shape[1]))
+        _req(dw, torch.float32, "dw", (dy.shape[1], x.shape[1]))
+        if db is not None:
+            _req(db, torch.float32, "db", (dy.shape[1],))
+        j = len(rows)
+        nwg = lib().ss_linear_wgrad_group_plan(x.shape[0], x.shape[1], dy.shape[1], ctypes.c_void_p(desc[j].ctypes.data))
+        if nwg <= 0 or len(rows) >= 128:
+            linear_wgrad_into(x, dy, dw, db)
+            continue
+        desc[j, 0], desc[j, 1], desc[j, 2] = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
+        desc[j, 3] = db.data_ptr() if db is not None else 0
+        desc[j, 4] = x.shape[0]
+        rows.append(j); starts.append(starts[-1] + nwg)
+    if not rows:
+        return
+    nprob = len(rows)
+    d_host = torch.from_numpy(desc[:nprob].copy()).pin_memory()
+    s_host = torch.tensor(starts, dtype=torch.int32).pin_memory()
+    d_dev, s_dev = d_host.to(dev, non_blocking=True), s_host.to(dev, non_blocking=True)
+    check(lib().ss_linear_wgrad_group(_p(d_dev), _p(s_dev), nprob, starts[-1], _stream()), "ss_linear_wgrad_group")
+    _GROUP_KEEP.append((d_host, s_host, d_dev, s_dev))
+    del _GROUP_KEEP[:-16]
+
+
 def linear_wgrad(x, dy, want_bias=False):
     """dW (n_out,k_in) f32 = dy^T @ x on the pipeline kernel (and db (n_out) f32 = column sums of dy when want_bias).
     x (m,k_in) bf16, dy (m,n_out) bf16.  dW and db share one zero-filled allocation."""

@@ -376,6 +376,14 @@ class PointTransformerV3(PointModule):
             plan.ready_event.record(stream)
         return plan
 
+    def _stage_linears(self, stage):
+        cache = self.__dict__.setdefault("_stage_linear_cache", {})
+        ls = cache.get(id(stage))
+        if ls is None:
+            ls = [m for m in stage.modules() if isinstance(m, nn.Linear)]
+            cache[id(stage)] = ls
+        return ls
+
     def _refresh_shadows(self):
         """bf16 copies of every Linear / SubMConv3d weight and Linear bias, refreshed with multi-tensor copies."""
         ps = self.__dict__.get("_shadow_lists")
@@ -463,6 +471,7 @@ class PointTransformerV3(PointModule):
         skips = []
         for s in range(self.num_stages):
             enc = getattr(self.enc, f"enc{s}")
+            SF.stage_begin(self._stage_linears(enc), levels[s].n)      # grouped weight gradients of the stage's Linears
             if s > 0:
                 skips.append(x)
                 x = enc.down(x, levels[s])
@@ -470,10 +479,12 @@ class PointTransformerV3(PointModule):
             for i in range(self.enc_depths[s]):
                 wc = self._want_copy and conv_dtype_for(x.shape[1]) == torch.bfloat16
                 x, xb = getattr(enc, f"block{i}")(x, x if xb is None else xb, levels[s], wc and i + 1 < self.enc_depths[s])
+            SF.stage_end()
         lv = self.num_stages - 1
         if not self.cls_mode:
             for s in reversed(range(self.num_stages - 1)):
                 dec = getattr(self.dec, f"dec{s}")
+                SF.stage_begin(self._stage_linears(dec), levels[s].n)
                 x, conv_in = dec.up(x, skips[s], levels[s + 1])
                 if s == 0 and self.training:
                     x = SF.defer_marker(x)       # backward leaves the full-resolution stage here: launch its queued wgrads
@@ -482,6 +493,7 @@ class PointTransformerV3(PointModule):
                     wc = self._want_copy and conv_dtype_for(x.shape[1]) == torch.bfloat16
                     x, xb = getattr(dec, f"block{i}")(x, conv_in if i == 0 else (x if xb is None else xb), levels[s],
                                                       wc and i + 1 < self.dec_depths[s])
+                SF.stage_end()
             lv = 0
             if self.training:
                 SF.defer_open()                  # backward starts in dec0: queue its weight gradients (see SF._Defer)

@@ -330,3 +330,55 @@ def test_gpu_sphere_crop_collect_collate_against_reference_semantics():
     gc = torch.floor(b["coord"] / 0.02).int()
     plan = build_plan(gc - gc.amin(0, keepdim=True), b["offset"], ("z", "hilbert"), (2,))
     assert plan.levels[0].n == 1400
+
+
+# ---- grouped Linear weight gradients ------------------------------------------------------------------------------------
+def test_linear_wgrad_group_matches_fp32_reference():
+    """ss_linear_wgrad_group: one launch for many (m, k, n) problems, ragged shapes, with and without bias sums."""
+    from scenesplat_amd import native as nv
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(1600, 256, 768), (1600, 256, 256), (1600, 256, 1024), (1600, 1024, 256), (6400, 128, 384), (2047, 64, 192),
+              (25600, 512, 512), (1024, 32, 96)]
+    items, refs = [], []
+    for i, (m, k, n) in enumerate(shapes):
+        x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
+        dy = torch.randn(m, n, device="cuda", generator=g).to(torch.bfloat16)
+        dw = torch.zeros(n, k, device="cuda")
+        db = torch.zeros(n, device="cuda") if i % 2 == 0 else None
+        items.append((x, dy, dw, db))
+        refs.append((dy.float().t() @ x.float(), dy.float().sum(0)))
+    nv.linear_wgrad_group(items)
+    torch.cuda.synchronize()
+    for (x, dy, dw, db), (rw, rb) in zip(items, refs):
+        assert (dw - rw).norm() <= 1e-5 * rw.norm(), (x.shape, dy.shape)
+        if db is not None:
+            assert (db - rb).norm() <= 1e-5 * rb.norm()
+
+
+def test_grouped_stage_wgrads_equal_per_layer_launches(monkeypatch):
+    """The stage identity node (functional._StageParams): parameter gradients of the tiny LangPretrainer with the Linear
+    weight gradients queued per stage and launched as groups equal those of one launch per layer."""
+    from scenesplat_amd import functional as SF
+    from scenesplat_amd import native as nv
+    d = _tiny_input(40, 2)
+    grads = {}
+    for mode, cap in (("grouped", 32768), ("single", 0)):
+        monkeypatch.setattr(SF, "WGRAD_GROUP_MAX_ROWS", cap)
+        model = _tiny_lang().train()
+        calls = []
+        orig = nv.linear_wgrad_group
+        monkeypatch.setattr(nv, "linear_wgrad_group", lambda items: (calls.append(len(items)), orig(items))[1])
+        with _Runtime(conv_dtype=torch.bfloat16, attn_impl=nv.ATTN_MFMA):
+            torch.manual_seed(9)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = model(dict(d))["loss"]
+            loss.backward()
+        monkeypatch.setattr(nv, "linear_wgrad_group", orig)
+        grads[mode] = {k: p.grad.clone() for k, p in model.named_parameters()}
+        if mode == "grouped":
+            assert sum(calls) >= 10 and len(calls) <= 5, calls         # a handful of launches carry the stage's Linears
+        else:
+            assert not calls
+    for k in grads["single"]:
+        a, b = grads["grouped"][k], grads["single"][k]
+        assert a.dtype == b.dtype and (a - b).norm() <= 2e-3 * b.norm() + 1e-7, (k, (a - b).norm() / b.norm())
