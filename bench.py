@@ -315,6 +315,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    t_enq = 0.0
     if os.environ.get("SS_BENCH_PER_STEP") == "1":      # DIAGNOSTIC: a device sync per step (perturbs the pipeline)
         for i in range(args.steps):
             t_ = time.perf_counter(); step(); torch.cuda.synchronize()
@@ -325,6 +326,7 @@ def main():
     else:
         for _ in range(args.steps):
             step()
+        t_enq = time.perf_counter() - t0       # host time to ENQUEUE the timed steps (diagnostic: host- vs GPU-bound)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -347,7 +349,7 @@ def main():
                        "gaussians_per_chunk": n, "chunks_per_gpu": 1,
                        "parallelism": "dp%d" % world, "attention_kernel": "mfma" if impl == nv.ATTN_MFMA else "simt"},
         }
-        log("timed %d steps: %.1f ms/step" % (args.steps, dt / args.steps * 1e3))
+        log("timed %d steps: %.1f ms/step (host enqueue %.1f ms/step)" % (args.steps, dt / args.steps * 1e3, t_enq / args.steps * 1e3))
         if world == 1:
             import gc
             state.clear()

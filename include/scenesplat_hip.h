@@ -161,6 +161,10 @@ int ss_ln_add_ln_bwd(const float* g_xout, const void* g_h, int g_h_dtype, const 
                      const float* stats, const float* gamma0, const float* gamma1, void* g_x, int g_x_dtype, void* g_t,
                      int g_t_dtype, float* part, int64_t n, int channels, int nblocks, ss_stream_t stream);
 int ss_add_layernorm_bwd_blocks(int64_t n);
+/* ONE launch reducing many partial-sum blocks (the dgamma / dbeta partials of a whole stage): desc (nprob, 4) int64 device =
+ * {part (K, nb, C) f32, dst (K*C) f32, nb, C | (K*C) << 32}; wg_start (nprob + 1) int32 device, problem p owns
+ * ceil(K*C / 256) workgroups; dst[k*C + c] = sum_b part[k][b][c]. */
+int ss_group_partial_sums(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups, ss_stream_t stream);
 /* g_v = g_xout + g_xcopy + LN'(g_h); g_x = g_v; g_y = rowscale*g_v; dgamma/dbeta partials (nblocks, C) */
 int ss_add_layernorm_bwd(const void* g_xout, int g_xout_dtype, const void* g_xcopy, int g_xcopy_dtype, const void* g_h,
                          int g_h_dtype, const void* v, int v_dtype, const float* mean, const float* rstd,

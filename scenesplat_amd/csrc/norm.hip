@@ -605,3 +605,40 @@ extern "C" int ss_bn_act_bwd_apply(const void* dy, int dy_dtype, const void* x, 
 #undef SS_BA
   return SS_OK;
 }
+
+
+// ---- grouped partial-sum reduction ------------------------------------------------------------------------------------
+// The backward seams above leave per-block partial sums of the affine gradients, part (K, nb, C) f32 (K = 2 or 4 parameter
+// vectors).  Reducing each with its own launch is 44 tiny kernels per step on the pooled levels; the stage identity node
+// (functional._StageParams) queues them and this kernel reduces ALL of a stage's partials in one launch.
+// desc: 4 int64 words per problem = {part, dst (K*C f32), nb, C | (K*C) << 32}; wg_start (nprob + 1): first workgroup.
+__global__ void __launch_bounds__(256)
+k_group_partial_sums(const int64_t* __restrict__ desc, const int32_t* __restrict__ wg_start, int nprob) {
+  const int b = blockIdx.x;
+  int p = 0;
+  while (p + 1 < nprob && wg_start[p + 1] <= b) ++p;
+  const int64_t* d = desc + (int64_t)p * 4;
+  const float* part = reinterpret_cast<const float*>(d[0]);
+  float* dst = reinterpret_cast<float*>(d[1]);
+  const int nb = (int)d[2];
+  const int C = (int)((uint64_t)d[3] & 0xffffffffu), KC = (int)((uint64_t)d[3] >> 32);
+  const int j = (b - wg_start[p]) * 256 + threadIdx.x;
+  if (j >= KC) return;
+  const int k = j / C, c = j - k * C;
+  const float* src = part + (int64_t)k * nb * C + c;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int bb = 0;
+  for (; bb + 4 <= nb; bb += 4) {
+    a0 += src[(int64_t)bb * C]; a1 += src[(int64_t)(bb + 1) * C]; a2 += src[(int64_t)(bb + 2) * C]; a3 += src[(int64_t)(bb + 3) * C];
+  }
+  for (; bb < nb; ++bb) a0 += src[(int64_t)bb * C];
+  dst[j] = (a0 + a1) + (a2 + a3);
+}
+
+extern "C" int ss_group_partial_sums(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups,
+                                     ss_stream_t stream) {
+  if (nprob <= 0 || total_workgroups <= 0) return SS_OK;
+  if (!desc || !wg_start) return SS_ERR_ARG;
+  SS_LAUNCH(k_group_partial_sums, dim3((unsigned)total_workgroups), dim3(256), 0, stream, desc, wg_start, nprob);
+  return SS_OK;
+}

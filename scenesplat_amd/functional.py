@@ -521,11 +521,14 @@ _STAGE = {"cur": None, "route": {}}
 
 class _WgradStage:
     def __init__(self):
-        self.queue = []
+        self.queue = []          # (x, dy, dW, db): nn.Linear weight gradients
+        self.redq = []           # (part (K, nb, C), dst (K, C)): LayerNorm dgamma / dbeta partial sums
 
     def flush(self):
         q, self.queue = self.queue, []
+        r, self.redq = self.redq, []
         nv.linear_wgrad_group(q)
+        nv.group_partial_sums(r)
 
 
 class _StageParams(torch.autograd.Function):
@@ -548,6 +551,7 @@ def stage_begin(linears, n_rows):
             and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16):
         return
     params = [p for m in linears for p in (m.weight, m.bias) if p is not None and p.requires_grad and p.dtype == torch.float32 and p.is_cuda]
+    # (the list holds the stage's nn.Linear AND nn.LayerNorm modules: both have .weight / .bias)
     if not params:
         return
     stage = _WgradStage()
@@ -557,6 +561,12 @@ def stage_begin(linears, n_rows):
 
 def stage_end():
     _STAGE["cur"], _STAGE["route"] = None, {}
+
+
+def _routed(p):
+    """(alias | p, stage | None) for a parameter that may be routed through the current stage's identity node."""
+    a = _STAGE["route"].get(id(p)) if (p is not None and _STAGE["route"]) else None
+    return (a, _STAGE["cur"]) if a is not None else (p, None)
 
 
 class _Linear(torch.autograd.Function):
@@ -650,16 +660,18 @@ def layer_norm(x, gamma, beta, eps=1e-5, out_dtype=None):
 
 
 class _AddLayerNorm(torch.autograd.Function):
-    """(x, y) -> xout = x + rowscale*y [fp32], h = LN(xout) [optional], xcopy = bf16(xout) [optional]."""
+    """(x, y) -> xout = x + rowscale*y [fp32], h = LN(xout) [optional], xcopy = bf16(xout) [optional].  stage: the
+    _WgradStage whose grouped launch reduces this seam's dgamma / dbeta partials (None: reduced here)."""
 
     @staticmethod
-    def forward(ctx, x, y, rowscale, gamma, beta, eps, want_copy, h_dtype):
+    def forward(ctx, x, y, rowscale, gamma, beta, eps, want_copy, h_dtype, stage):
         x, y = x.contiguous(), y.contiguous()
         g32 = gamma.float().contiguous() if gamma is not None else None
         b32 = beta.float().contiguous() if beta is not None else None
         xout, xcopy, h, mean, rstd = nv.add_layernorm_fwd(x, y, rowscale, g32, b32, eps, True, want_copy, h_dtype)
         ctx.save_for_backward(xout, mean, rstd, g32, rowscale)
         ctx.meta = (x.dtype, y.dtype, gamma.dtype if gamma is not None else None)
+        ctx.stage = stage
         ctx.set_materialize_grads(False)
         return xout, h, xcopy
 
@@ -671,22 +683,31 @@ class _AddLayerNorm(torch.autograd.Function):
         g_h = g_h.contiguous() if g_h is not None else None
         g_xcopy = g_xcopy.contiguous() if g_xcopy is not None else None
         if g_xout is None and g_h is None and g_xcopy is None:
-            return None, None, None, None, None, None, None, None
+            return (None,) * 9
+        if ctx.stage is not None and g_dt == torch.float32:
+            g_x, g_y, part, _ = nv.add_layernorm_bwd(g_xout, g_xcopy, g_h, xout, mean, rstd, g32, rowscale, x_dt, y_dt, reduce=False)
+            dg = db = None
+            if part is not None:
+                dst = torch.empty((2, part.shape[2]), dtype=torch.float32, device=part.device)
+                ctx.stage.redq.append((part, dst))
+                dg, db = dst[0], dst[1]
+            return g_x, g_y, None, dg, db, None, None, None, None
         g_x, g_y, dg, db = nv.add_layernorm_bwd(g_xout, g_xcopy, g_h, xout, mean, rstd, g32, rowscale, x_dt, y_dt)
         return (g_x, g_y, None, dg.to(g_dt) if dg is not None else None, db.to(g_dt) if db is not None else None,
-                None, None, None)
+                None, None, None, None)
 
 
 class _LnAddLn(torch.autograd.Function):
     """First seam of a pre-norm Block: (x, t) -> xout = x + LN0(t) [fp32], h = LN1(xout); one kernel each way."""
 
     @staticmethod
-    def forward(ctx, x, t, g0, b0, eps0, g1, b1, eps1, h_dtype):
+    def forward(ctx, x, t, g0, b0, eps0, g1, b1, eps1, h_dtype, stage):
         x, t = x.contiguous(), t.contiguous()
         p32 = [p.float().contiguous() for p in (g0, b0, g1, b1)]
         xout, h, stats = nv.ln_add_ln_fwd(x, t, p32[0], p32[1], eps0, p32[2], p32[3], eps1, h_dtype)
         ctx.save_for_backward(xout, t, stats, p32[0], p32[2])
         ctx.meta = (x.dtype, t.dtype, g0.dtype)
+        ctx.stage = stage
         ctx.set_materialize_grads(False)
         return xout, h
 
@@ -695,21 +716,34 @@ class _LnAddLn(torch.autograd.Function):
         xout, t, stats, g0, g1 = ctx.saved_tensors
         x_dt, t_dt, p_dt = ctx.meta
         if g_xout is None and g_h is None:
-            return (None,) * 9
+            return (None,) * 10
         g_xout = g_xout.float().contiguous() if g_xout is not None else None
         g_h = g_h.contiguous() if g_h is not None else None
+        if ctx.stage is not None and p_dt == torch.float32:
+            g_x, g_t, part = nv.ln_add_ln_bwd(g_xout, g_h, xout, t, stats, g0, g1, x_dt, t_dt, reduce=False)
+            dst = torch.empty((4, part.shape[2]), dtype=torch.float32, device=part.device)
+            ctx.stage.redq.append((part, dst))
+            return g_x, g_t, dst[0], dst[1], None, dst[2], dst[3], None, None, None
         g_x, g_t, dg0, db0, dg1, db1 = nv.ln_add_ln_bwd(g_xout, g_h, xout, t, stats, g0, g1, x_dt, t_dt)
-        return g_x, g_t, dg0.to(p_dt), db0.to(p_dt), None, dg1.to(p_dt), db1.to(p_dt), None, None
+        return g_x, g_t, dg0.to(p_dt), db0.to(p_dt), None, dg1.to(p_dt), db1.to(p_dt), None, None, None
 
 
 def ln_add_ln(x, t, ln0, ln1, h_dtype=torch.float32):
     """x + LayerNorm0(t) and LayerNorm1 of the sum, fused (ln0 / ln1: nn.LayerNorm modules with affine parameters)."""
-    return _LnAddLn.apply(x, t, ln0.weight, ln0.bias, ln0.eps, ln1.weight, ln1.bias, ln1.eps, h_dtype)
+    (g0, s0), (b0, s1), (g1, s2), (b1, s3) = _routed(ln0.weight), _routed(ln0.bias), _routed(ln1.weight), _routed(ln1.bias)
+    stage = s0 if (s0 is not None and s0 is s1 and s0 is s2 and s0 is s3) else None
+    if stage is None:
+        g0, b0, g1, b1 = ln0.weight, ln0.bias, ln1.weight, ln1.bias
+    return _LnAddLn.apply(x, t, g0, b0, ln0.eps, g1, b1, ln1.eps, h_dtype, stage)
 
 
 def add_layer_norm(x, y, rowscale=None, gamma=None, beta=None, eps=1e-5, want_copy=False, h_dtype=torch.float32):
     """Fused residual seam: returns (xout fp32, h or None, bf16 copy of xout or None)."""
-    return _AddLayerNorm.apply(x, y, rowscale, gamma, beta, eps, want_copy, h_dtype)
+    (ga, s0), (be, s1) = _routed(gamma), _routed(beta)
+    stage = s0 if (s0 is not None and s0 is s1) else None
+    if stage is None:
+        ga, be = gamma, beta
+    return _AddLayerNorm.apply(x, y, rowscale, ga, be, eps, want_copy, h_dtype, stage)
 
 
 class _BatchNormAct(torch.autograd.Function):

@@ -16,6 +16,9 @@ HAVE_MFMA_ATTN = True  # bf16 MFMA window attention (csrc/attention_mfma.hip)
 ORDER_IDS = {"z": 0, "z-trans": 1, "hilbert": 2, "hilbert-trans": 3}
 
 
+_GROUP_KEEP = []      # descriptor tensors of the last grouped launches (kept alive until the copies have certainly run)
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -312,9 +315,6 @@ def linear_wgrad_into(x, dy, dw, db):
     check(lib().ss_linear_wgrad(_p(x), _p(dy), _p(dw), _p(db), m, k, nout, _stream()), "ss_linear_wgrad")
 
 
-_GROUP_KEEP = []      # descriptor tensors of the last grouped launches (kept alive until the copies have certainly run)
-
-
 def linear_wgrad_group(items):
     """ONE launch for many nn.Linear weight gradients.  items: list of (x (m,k) bf16, dy (m,n) bf16, dw (n,k) f32 ZEROED,
     db (n) f32 ZEROED | None).  Problems the pipeline kernel cannot take are run one by one."""
@@ -404,8 +404,29 @@ def ln_add_ln_fwd(x, t, gamma0, beta0, eps0, gamma1, beta1, eps1, h_dtype):
     return xout, h, stats
 
 
-def ln_add_ln_bwd(g_xout, g_h, xout, t, stats, gamma0, gamma1, gx_dtype, gt_dtype):
-    """-> (g_x, g_t, dgamma0, dbeta0, dgamma1, dbeta1)"""
+def group_partial_sums(items):
+    """ONE launch for many partial-sum reductions.  items: list of (part (K, nb, C) f32, dst (K, C) f32): dst = part.sum(1)."""
+    import numpy as np
+    if not items:
+        return
+    dev = items[0][0].device
+    desc = np.zeros((len(items), 4), dtype=np.int64)
+    starts = [0]
+    for j, (part, dst) in enumerate(items):
+        K, nb, C = part.shape
+        _req(part, torch.float32, "part"); _req(dst, torch.float32, "dst", (K, C))
+        desc[j] = (part.data_ptr(), dst.data_ptr(), nb, C | ((K * C) << 32))
+        starts.append(starts[-1] + (K * C + 255) // 256)
+    d_host = torch.from_numpy(desc).pin_memory()
+    s_host = torch.tensor(starts, dtype=torch.int32).pin_memory()
+    d_dev, s_dev = d_host.to(dev, non_blocking=True), s_host.to(dev, non_blocking=True)
+    check(lib().ss_group_partial_sums(_p(d_dev), _p(s_dev), len(items), starts[-1], _stream()), "ss_group_partial_sums")
+    _GROUP_KEEP.append((d_host, s_host, d_dev, s_dev))
+    del _GROUP_KEEP[:-16]
+
+
+def ln_add_ln_bwd(g_xout, g_h, xout, t, stats, gamma0, gamma1, gx_dtype, gt_dtype, reduce=True):
+    """-> (g_x, g_t, dgamma0, dbeta0, dgamma1, dbeta1); reduce=False: (g_x, g_t, part (4, nb, C)) for a grouped reduction"""
     n, C = xout.shape
     dev = xout.device
     if g_xout is not None:
@@ -418,12 +439,14 @@ def ln_add_ln_bwd(g_xout, g_h, xout, t, stats, gamma0, gamma1, gx_dtype, gt_dtyp
     part = torch.empty((4, nb, C), dtype=torch.float32, device=dev)
     check(lib().ss_ln_add_ln_bwd(_p(g_xout), _p(g_h), _dt(g_h), _p(xout), _p(t), _dt(t), _p(stats), _p(gamma0), _p(gamma1), _p(g_x),
                                  _dt(g_x), _p(g_t), _dt(g_t), _p(part), n, C, nb, _stream()), "ss_ln_add_ln_bwd")
+    if not reduce:
+        return g_x, g_t, part
     red = part.sum(1)
     return g_x, g_t, red[0], red[1], red[2], red[3]
 
 
-def add_layernorm_bwd(g_xout, g_xcopy, g_h, v, mean, rstd, gamma, rowscale, gx_dtype, gy_dtype):
-    """-> (g_x | None, g_y | None, dgamma | None, dbeta | None)"""
+def add_layernorm_bwd(g_xout, g_xcopy, g_h, v, mean, rstd, gamma, rowscale, gx_dtype, gy_dtype, reduce=True):
+    """-> (g_x | None, g_y | None, dgamma | None, dbeta | None); reduce=False: (g_x, g_y, part (2, nb, C) | None, None)"""
     ref = g_h if g_h is not None else (g_xout if g_xout is not None else g_xcopy)
     n, C = ref.shape
     dev = ref.device
@@ -442,6 +465,8 @@ def add_layernorm_bwd(g_xout, g_xcopy, g_h, v, mean, rstd, gamma, rowscale, gx_d
                                      _p(mean), _p(rstd), _p(gamma), _p(rowscale), _p(g_x), _dt(g_x), _p(g_y), _dt(g_y),
                                      _p(dgp), _p(dbp), n, C, nb, _stream()), "ss_add_layernorm_bwd")
     if g_h is not None:
+        if not reduce:
+            return g_x, g_y, part, None
         red = part.sum(1)
         return g_x, g_y, red[0], red[1]
     return g_x, g_y, None, None

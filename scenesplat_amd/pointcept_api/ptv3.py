@@ -380,7 +380,7 @@ class PointTransformerV3(PointModule):
         cache = self.__dict__.setdefault("_stage_linear_cache", {})
         ls = cache.get(id(stage))
         if ls is None:
-            ls = [m for m in stage.modules() if isinstance(m, nn.Linear)]
+            ls = [m for m in stage.modules() if isinstance(m, (nn.Linear, nn.LayerNorm))]
             cache[id(stage)] = ls
         return ls
 
