@@ -38,6 +38,8 @@ def parse():
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--cpu-n-side", type=int, default=256, help="room side of the CPU-baseline chunk (256 -> the metric's 102,400 Gaussians, about a minute on 16 cores)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay forward+backward as a hipGraph once the plan shape repeats (auto: single-rank runs)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline traffic = null)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-3 and fp32-conv secondary lines")
     return ap.parse_args()
@@ -284,14 +286,27 @@ def main():
     side = torch.cuda.Stream()
     state = {"plan": model.prepare_plan(data, stream=side)}
 
+    cot16 = cot.to(torch.bfloat16)
+
+    def fwd_bwd(plan, t):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = net(dict(feat=t["feat"], grid_coord=data["grid_coord"], offset=data["offset"], plan=plan))
+        # backward from the seeded random cotangent, fed directly as the output gradient (no loss kernels)
+        torch.autograd.backward(out.feat, grad_tensors=t["cot"])
+        return {"feat": out.feat}
+
+    # Steady state (scenesplat_amd/steady_state.py): every chunk of the room has the same plan SHAPE, so after two eager
+    # steps the ~1,100 launches of forward + backward are captured in a hipGraph and later steps replay it -- the plan is
+    # still built anew every step (on the side stream) and copied into the captured plan's tensors; every kernel still
+    # runs.  With more than one rank the step stays eager: DDP's bucket hooks are host callbacks.
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    from scenesplat_amd.steady_state import SteadyStateStep
+    steady = SteadyStateStep(fwd_bwd, list(model.parameters()), warmup=1, enabled=use_graph)
+
     def step():
         net.zero_grad(set_to_none=True)
         plan, state["plan"] = state["plan"], None
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            out = net(dict(feat=data["feat"], grid_coord=data["grid_coord"], offset=data["offset"], plan=plan))
-        state["prev"] = plan
-        # backward from the seeded random cotangent, fed directly as the output gradient (no loss kernels)
-        torch.autograd.backward(out.feat, grad_tensors=cot.to(out.feat.dtype))
+        steady(plan, {"feat": data["feat"], "cot": cot16})
         # SS_BENCH_REUSE_PLAN=1 is a DIAGNOSTIC (host- vs GPU-bound?): it skips the per-step plan build and the line it
         # prints is not the metric
         state["plan"] = plan if os.environ.get("SS_BENCH_REUSE_PLAN") == "1" else model.prepare_plan(data, stream=side)
@@ -305,6 +320,12 @@ def main():
     for i in range(max(args.warmup, 3)):
         t_ = time.perf_counter(); step(); torch.cuda.synchronize()
         log("warmup step %d: %.1f ms" % (i, (time.perf_counter() - t_) * 1e3))
+    # the steady-state path needs an eager step, a sync-checked eager step and the capturing step before it replays: all
+    # of them belong to the warm-up, never to the timed region
+    extra = 0
+    while use_graph and steady.replays == 0 and steady.refused is None and extra < 4:
+        t_ = time.perf_counter(); step(); torch.cuda.synchronize(); extra += 1
+        log("extra warmup step (graph capture): %.1f ms" % ((time.perf_counter() - t_) * 1e3))
     torch.cuda.synchronize()
     if os.environ.get("SS_BENCH_GC", "freeze") == "freeze":
         # one full collection now, then keep the survivors out of later generation-2 scans: a step allocates ~10^5
@@ -314,6 +335,10 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if use_graph:
+        log("steady state: %d replays, %d eager steps so far%s" % (steady.replays, steady.eager_steps,
+                                                                     "; capture REFUSED: " + steady.refused if steady.refused else ""))
+    replays_before = steady.replays
     t0 = time.perf_counter()
     t_enq = 0.0
     if os.environ.get("SS_BENCH_PER_STEP") == "1":      # DIAGNOSTIC: a device sync per step (perturbs the pipeline)
@@ -347,7 +372,9 @@ def main():
                                     + " PT-v3m1 lang-pretrain encoder (91.71M params, in=11, out=768) fwd+bwd, "
                                     "1 chunk of %d Gaussians per GPU per step, serialization included") % (n, n),
                        "gaussians_per_chunk": n, "chunks_per_gpu": 1,
-                       "parallelism": "dp%d" % world, "attention_kernel": "mfma" if impl == nv.ATTN_MFMA else "simt"},
+                       "parallelism": "dp%d" % world, "attention_kernel": "mfma" if impl == nv.ATTN_MFMA else "simt",
+                       "execution": ("hipGraph replay of forward+backward (%d of the %d timed steps; plan rebuilt and copied in every step)"
+                                     % (steady.replays - replays_before, args.steps)) if steady.replays > replays_before else "eager launches"},
         }
         log("timed %d steps: %.1f ms/step (host enqueue %.1f ms/step)" % (args.steps, dt / args.steps * 1e3, t_enq / args.steps * 1e3))
         if world == 1:

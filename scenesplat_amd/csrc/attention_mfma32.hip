@@ -17,6 +17,7 @@
 //   * staging addresses: per thread three (row, column) pairs fixed before the loop, the window's gather offsets
 //     sit in LDS padded to a multiple of 64 rows: one ds_read + one 64-bit shift-add per 16-byte load.
 #include "attention_internal.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
 typedef __attribute__((ext_vector_type(4))) short s4_t;
@@ -55,6 +56,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;   // native 16
 #define FA32_IDX_CAP SS_ATTN_MFMA_MAX_WINDOW
 #ifndef FA32_ABL
 #define FA32_ABL 0     // ablation bitmask of scripts/ubench/attn_bench.hip (diagnostic builds only; 0 in the library)
+#endif
+
+#ifdef FA32_CLOCK
+// diagnostic build only (scripts/ubench/attn_bench.hip -DFA32_CLOCK): shader-clock and 100 MHz real-time stamps around the
+// tile loop of wave 0 of every workgroup -> in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz
+__device__ unsigned long long fa32_stamp[4 * 32768];
 #endif
 
 template <int D> struct A32 {
@@ -309,6 +316,9 @@ k_attn_fwd_mfma32(const unsigned short* __restrict__ qkv, const int32_t* __restr
   };
 
   __syncthreads();                   // gidx_s ready
+#ifdef FA32_CLOCK
+  unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rk0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #if FA32_PIPE
   // prologue: K(0), V(0) -> images 0; K(1) -> K image 1 (V(0) is simply written twice); S(0) and its maximum
   fa32_tile_write<NLD>(stg, Kimg(0), Vimg(0), st_isv, st_lds);
@@ -355,6 +365,12 @@ k_attn_fwd_mfma32(const unsigned short* __restrict__ qkv, const int32_t* __restr
     softmax_pv(sc, Vimg(b));
     if (t + 1 < ntiles && !(FA32_ABL & 1)) fa32_tile_write<NLD>(stg, Kimg(b ^ 1), Vimg(b ^ 1), st_isv, st_lds);
     if (!(FA32_ABL & 2)) __syncthreads();
+  }
+#endif
+#ifdef FA32_CLOCK
+  if (tid == 0 && blockIdx.x < 32768) {
+    fa32_stamp[4 * blockIdx.x + 0] = ck0; fa32_stamp[4 * blockIdx.x + 1] = rk0;
+    fa32_stamp[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime(); fa32_stamp[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
   // ---- epilogue: row sums, lse, normalised output rows

@@ -396,10 +396,13 @@ def refresh_shadows(src, dst):
     """Re-cast the parameters whose value changed since their shadow was written (all of them after an optimizer
     step: one multi-tensor copy; none on a repeated forward)."""
     todo_s, todo_d = [], []
+    # inside a hipGraph capture every shadow is re-cast: the replayed step must pick up whatever the optimizer wrote
+    # since the previous replay, and a copy skipped now would be missing from the graph for good
+    everything = torch.cuda.is_current_stream_capturing()
     for p, d in zip(src, dst):
         ent = _SHADOW.get(p)
         st = _stamp(p)
-        if ent is None or ent[0] is not d or ent[1] != st:
+        if everything or ent is None or ent[0] is not d or ent[1] != st:
             todo_s.append(p); todo_d.append(d)
             if ent is not None and ent[0] is d:
                 ent[1] = st
@@ -561,6 +564,15 @@ def stage_begin(linears, n_rows):
 
 def stage_end():
     _STAGE["cur"], _STAGE["route"] = None, {}
+
+
+def reset_state():
+    """Forget everything a forward pass leaves between its calls (the open stage, queued weight gradients, the remembered
+    head sums): called after a forward / backward that ended in an exception, e.g. a refused hipGraph capture."""
+    stage_end()
+    _Defer.open = _Defer.armed = False
+    _Defer.queue.clear()
+    _HEAD_CACHE.clear()
 
 
 def _routed(p):

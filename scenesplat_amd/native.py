@@ -19,6 +19,48 @@ ORDER_IDS = {"z": 0, "z-trans": 1, "hilbert": 2, "hilbert-trans": 3}
 _GROUP_KEEP = []      # descriptor tensors of the last grouped launches (kept alive until the copies have certainly run)
 
 
+class DescriptorPool:
+    """Pinned host memory for the descriptors of grouped launches issued INSIDE a hipGraph capture (steady_state.py).
+    The captured host-to-device copy re-reads its source on every replay, so the source must live, unchanged, as long as
+    the graph does; and pinned memory cannot be allocated while a stream is capturing.  The pool is allocated before the
+    capture begins and owned by the captured step."""
+
+    def __init__(self, nbytes=1 << 20):
+        self.buf = torch.empty(int(nbytes), dtype=torch.uint8).pin_memory()
+        self.off = 0
+        self.device_side = []
+
+    def take(self, arr):
+        nb = arr.nbytes
+        off = (self.off + 63) & ~63
+        if off + nb > self.buf.numel():
+            raise RuntimeError("descriptor pool of the captured step is full")
+        self.off = off + nb
+        view = self.buf[off:off + nb]
+        view.numpy()[:] = arr.reshape(-1).view("uint8")
+        return view.view(_NP2T[arr.dtype.name]).view(arr.shape)
+
+
+_NP2T = {"int64": torch.int64, "int32": torch.int32}
+CAPTURE_POOL = None   # a DescriptorPool while a capture is open
+
+
+def _upload_descriptors(desc, starts, dev):
+    """(descriptor rows, first-workgroup table) -> device tensors through pinned memory, without a stream sync."""
+    import numpy as np
+    starts = np.asarray(starts, dtype=np.int32)
+    if CAPTURE_POOL is not None and torch.cuda.is_current_stream_capturing():
+        d_host, s_host = CAPTURE_POOL.take(desc), CAPTURE_POOL.take(starts)
+        d_dev, s_dev = d_host.to(dev, non_blocking=True), s_host.to(dev, non_blocking=True)
+        CAPTURE_POOL.device_side.append((d_dev, s_dev))
+        return d_dev, s_dev
+    d_host, s_host = torch.from_numpy(desc).pin_memory(), torch.from_numpy(starts).pin_memory()
+    d_dev, s_dev = d_host.to(dev, non_blocking=True), s_host.to(dev, non_blocking=True)
+    _GROUP_KEEP.append((d_host, s_host, d_dev, s_dev))
+    del _GROUP_KEEP[:-16]
+    return d_dev, s_dev
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -342,12 +384,8 @@ def linear_wgrad_group(items):
     if not rows:
         return
     nprob = len(rows)
-    d_host = torch.from_numpy(desc[:nprob].copy()).pin_memory()
-    s_host = torch.tensor(starts, dtype=torch.int32).pin_memory()
-    d_dev, s_dev = d_host.to(dev, non_blocking=True), s_host.to(dev, non_blocking=True)
+    d_dev, s_dev = _upload_descriptors(desc[:nprob].copy(), starts, dev)
     check(lib().ss_linear_wgrad_group(_p(d_dev), _p(s_dev), nprob, starts[-1], _stream()), "ss_linear_wgrad_group")
-    _GROUP_KEEP.append((d_host, s_host, d_dev, s_dev))
-    del _GROUP_KEEP[:-16]
 
 
 def linear_wgrad(x, dy, want_bias=False):
@@ -417,12 +455,8 @@ def group_partial_sums(items):
         _req(part, torch.float32, "part"); _req(dst, torch.float32, "dst", (K, C))
         desc[j] = (part.data_ptr(), dst.data_ptr(), nb, C | ((K * C) << 32))
         starts.append(starts[-1] + (K * C + 255) // 256)
-    d_host = torch.from_numpy(desc).pin_memory()
-    s_host = torch.tensor(starts, dtype=torch.int32).pin_memory()
-    d_dev, s_dev = d_host.to(dev, non_blocking=True), s_host.to(dev, non_blocking=True)
+    d_dev, s_dev = _upload_descriptors(desc, starts, dev)
     check(lib().ss_group_partial_sums(_p(d_dev), _p(s_dev), len(items), starts[-1], _stream()), "ss_group_partial_sums")
-    _GROUP_KEEP.append((d_host, s_host, d_dev, s_dev))
-    del _GROUP_KEEP[:-16]
 
 
 def ln_add_ln_bwd(g_xout, g_h, xout, t, stats, gamma0, gamma1, gx_dtype, gt_dtype, reduce=True):

@@ -176,6 +176,75 @@ class ScenePlan:
                     elif isinstance(t, WindowIndex):
                         yield t.gidx; yield t.sidx
 
+    # -- steady-state replay (scenesplat_amd/steady_state.py) ------------------------------------------------------
+    # A captured hipGraph holds the ADDRESSES of the plan tensors it was captured with.  A later batch whose plan has the
+    # same host-side shape (level sizes, offsets, window layout: `signature`) is run by copying its tensors into those
+    # addresses (`load_from`) and replaying.  Tensors are matched by ROLE.  The float pipeline reads a plan through
+    # window(slot j, patch), indices / idx_ptr / cluster and the conv tables only; window indices are matched by SLOT
+    # (shuffle_orders draws a new curve permutation per batch: slot j of the captured plan receives slot j of the new
+    # one, whatever curve that is this step), everything else by name.
+    def _slots(self):
+        """-> list of (role, tensor)."""
+        out = []
+        for li, lv in enumerate(self.levels):
+            for name in ("grid_coord", "batch", "codes", "order", "inverse", "codes_sorted", "cluster", "idx_ptr", "indices"):
+                t = getattr(lv, name)
+                if t is not None:
+                    out.append(((li, name), t))
+            for key, v in lv._windows.items():
+                if key[0] == "layout":
+                    for i, t in enumerate(v[:3]):
+                        out.append(((li, "layout", key[1], i), t))
+                else:
+                    slot = lv.curves.index(key[0])
+                    out.append(((li, "window", slot, key[1], "gidx", v.num_windows, v.max_window, v.n_pad), v.gidx))
+                    out.append(((li, "window", slot, key[1], "sidx"), v.sidx))
+            for key, v in lv._nbr.items():
+                for i, t in enumerate(v if isinstance(v, tuple) else (v,)):
+                    if isinstance(t, torch.Tensor):
+                        out.append(((li, "nbr", key, i), t))
+        return out
+
+    def signature(self):
+        """Hashable host-side shape of the plan; equal signatures <=> `load_from` is valid."""
+        head = (tuple(self.order_names),) + tuple((lv.n, tuple(lv.offsets), lv.depth, bool(lv.has_duplicates), len(lv.curves))
+                                                  for lv in self.levels)
+        return head + tuple((role, tuple(t.shape), str(t.dtype)) for role, t in self._slots())
+
+    def own_storage(self):
+        """Give `indices` (a row of the finer level's order buffer) and the conv walk order (a row of `order` on small
+        levels) storage of their own, so that `load_from` can fill every role independently.  Called once on the plan a
+        graph is captured with."""
+        for lv in self.levels:
+            if lv.indices is not None:
+                lv.indices = lv.indices.clone()
+            rp = lv._nbr.get("rowperm")
+            if rp is not None:
+                lv._nbr["rowperm"] = rp.clone()
+        return self
+
+    @torch.no_grad()
+    def load_from(self, other):
+        """Copy the tensors of `other` (same signature) into this plan's tensors on the current stream, one multi-tensor
+        copy per dtype.  Host-side fields stay: they are equal by signature, except the curve permutation, which only
+        names the window slots."""
+        if other.ready_event is not None:
+            torch.cuda.current_stream().wait_event(other.ready_event)
+            other.record_stream(torch.cuda.current_stream())
+            other.ready_event = None
+        mine, theirs = self._slots(), other._slots()
+        if len(mine) != len(theirs):
+            raise ValueError("load_from: plans differ in structure")
+        by_dtype = {}
+        for (ra, ta), (rb, tb) in zip(mine, theirs):
+            if ra != rb or ta.shape != tb.shape or ta.dtype != tb.dtype:
+                raise ValueError(f"load_from: plans differ at {ra} vs {rb}")
+            if ta.numel():
+                d_list, s_list = by_dtype.setdefault(ta.dtype, ([], []))
+                d_list.append(ta); s_list.append(tb)
+        for d_list, s_list in by_dtype.values():
+            torch._foreach_copy_(d_list, s_list)
+
     def materialize(self, window_specs=(), kernel_sizes=()):
         """Build the lazily cached pieces now (on the current stream): window_specs = [(level, curve index,
         patch)], kernel_sizes = [(level, k)]."""

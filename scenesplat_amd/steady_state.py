@@ -1,0 +1,160 @@
+"""Steady-state replay: forward + backward of a batch whose integer plan has a shape seen before, as ONE hipGraph launch.
+
+The float pipeline of a PT-v3m1 step is ~1,100 kernel launches whose shapes depend only on the host-side shape of the
+batch's ScenePlan (level sizes, batch offsets, window layout).  When batches repeat that shape -- fixed-size chunks of one
+scene, the evaluator's chunk_size slices, the synthetic room of bench.py -- the launches are captured once with
+`torch.cuda.graph` (a hipGraph on ROCm) and later steps copy their plan tensors and inputs into the captured addresses
+(ScenePlan.load_from: one multi-tensor copy per dtype) and replay: the host enqueues a plan build, two copies and one
+graph launch instead of a thousand kernels.  Batches with any other shape run eagerly, as does everything when
+capture is refused (a host read inside the step, e.g. the per-class loop of AggregatedContrastiveLoss: found by one eager step under
+torch's sync detector before any capture is attempted).
+
+What is inside the graph is exactly what the eager step launches: the bf16 parameter shadows are re-cast from the fp32
+parameters at the top of every replay (functional.refresh_shadows), dropout / DropPath draws advance the Philox offset of
+the default generator per replay (torch registers it with the graph), and the parameter gradients are (re)written -- not
+accumulated -- by every replay into the tensors the capture allocated; `param.grad` is pointed at them after each replay,
+so an optimizer step between replays works as usual.  Gradient accumulation over several micro-batches and
+DistributedDataParallel (its bucket hooks are host callbacks) are outside this path: the caller uses the eager step.
+
+No part of the reference corresponds to this file: the reference launches every kernel of every step from Python
+(pointcept/engines/train.py:142-196)."""
+import os
+import warnings
+
+import torch
+
+from . import functional as SF
+from . import native as nv
+
+
+class _Captured:
+    __slots__ = ("graph", "plan", "inputs", "outputs", "grads", "keep")
+
+
+class SteadyStateStep:
+    """step = SteadyStateStep(fn, params); out = step(plan, {"feat": ..., ...})
+
+    fn(plan, inputs) -> dict of tensors: the eager forward + backward (it must not synchronise with the host); the step
+        returns them detached;
+    params: the parameters whose .grad the step writes (their .grad is cleared before a capture);
+    warmup: eager runs of a signature before it is captured (allocator pools, hipBLASLt heuristics, lazy code objects);
+    max_graphs: signatures kept (least recently used is dropped; a captured step owns its activations' memory)."""
+
+    def __init__(self, fn, params, warmup=2, max_graphs=2, enabled=True):
+        self.fn, self.params = fn, list(params)
+        self.warmup, self.max_graphs, self.enabled = int(warmup), int(max_graphs), bool(enabled)
+        self._seen, self._graphs = {}, {}
+        self.refused = None            # repr of the exception that ended a capture: eager from then on
+        self._checked = False
+        self.replays = self.eager_steps = 0
+
+    @staticmethod
+    def _signature(plan, inputs):
+        return (plan.signature(),) + tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(inputs.items()))
+
+    def _eager(self, plan, inputs):
+        # outputs are handed out DETACHED: a caller holding on to them must not keep this step's autograd graph alive
+        self.eager_steps += 1
+        return {k: v.detach() for k, v in self.fn(plan, inputs).items()}
+
+    def __call__(self, plan, inputs):
+        if not self.enabled or self.refused is not None:
+            return self._eager(plan, inputs)
+        sig = self._signature(plan, inputs)
+        cap = self._graphs.get(sig)
+        if cap is None:
+            if len(self._seen) > 256:                          # batches of ever-changing shape: forget the counts
+                self._seen.clear()
+            self._seen[sig] = self._seen.get(sig, 0) + 1
+            if self._seen[sig] <= self.warmup:
+                return self._eager(plan, inputs)
+            if not self._checked:
+                # One eager step on a SIDE stream with torch's sync detector armed, BEFORE any capture is attempted: what
+                # would poison a capture -- a host read (.item(), .cpu(), a blocking copy), or an autograd graph of an
+                # earlier step that is still referenced (its AccumulateGrad nodes belong to the default stream, which a
+                # capturing stream must not touch) -- shows up here, where nothing needs unwinding.  (A capture that fails
+                # half way cannot be unwound on this stack: ending an invalidated capture crashes inside the runtime.)
+                self._checked = True
+                main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+                side.wait_stream(main)
+                torch.cuda.set_sync_debug_mode("error")
+                try:
+                    with warnings.catch_warnings(record=True) as seen, torch.cuda.stream(side):
+                        warnings.simplefilter("always")
+                        out = self._eager(plan, inputs)
+                    stale = [w for w in seen if "AccumulateGrad node's stream" in str(w.message)]
+                    if stale:
+                        raise RuntimeError("an autograd graph of an earlier step is still referenced (keep only detached "
+                                           "outputs between steps): " + str(stale[0].message)[:120])
+                    main.wait_stream(side)
+                    return out
+                except Exception as e:  # noqa: BLE001
+                    main.wait_stream(side)
+                    self._refuse(e)
+                    return self._eager(plan, inputs)
+                finally:
+                    torch.cuda.set_sync_debug_mode("default")
+            try:
+                cap = self._capture(plan, inputs)
+            except Exception as e:  # noqa: BLE001 -- whatever refused the capture, the eager step still works
+                self._refuse(e)
+                return self._eager(plan, inputs)
+            self._graphs[sig] = cap
+            while len(self._graphs) > self.max_graphs:
+                self._graphs.pop(next(iter(self._graphs)))
+        else:
+            self._graphs[sig] = self._graphs.pop(sig)          # most recently used last
+            cap.plan.load_from(plan)
+            names = sorted(inputs)
+            torch._foreach_copy_([cap.inputs[k] for k in names], [inputs[k] for k in names])
+        cap.graph.replay()
+        for p, g in cap.grads:
+            p.grad = g
+        self.replays += 1
+        return cap.outputs
+
+    def _refuse(self, exc):
+        self.refused = repr(exc)
+        SF.reset_state()
+        for p in self.params:
+            p.grad = None
+        torch.cuda.synchronize()
+
+    def _capture(self, plan, inputs):
+        cap = _Captured()
+        if plan.ready_event is not None:
+            torch.cuda.current_stream().wait_event(plan.ready_event)
+            plan.record_stream(torch.cuda.current_stream())
+            plan.ready_event = None
+        cap.plan = plan.own_storage()
+        cap.inputs = {k: v.clone() for k, v in inputs.items()}
+        for p in self.params:
+            p.grad = None
+        cap.keep = nv.DescriptorPool()
+        cap.graph = torch.cuda.CUDAGraph()
+        main = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        nv.CAPTURE_POOL = cap.keep
+        try:
+            # capture_begin / capture_end by hand (not `with torch.cuda.graph`): when the step raises, the capture is still
+            # ended and the stream context restored before the exception travels on
+            with torch.cuda.stream(side):
+                cap.graph.capture_begin()
+                try:
+                    cap.outputs = {k: v.detach() for k, v in self.fn(cap.plan, cap.inputs).items()}
+                except BaseException:
+                    if os.environ.get("SS_STEADY_DEBUG"):
+                        import traceback
+                        traceback.print_exc()
+                    try:
+                        cap.graph.capture_end()
+                    except Exception:  # noqa: BLE001 -- an invalidated capture reports its error once more here
+                        pass
+                    raise
+                cap.graph.capture_end()
+        finally:
+            nv.CAPTURE_POOL = None
+        main.wait_stream(side)
+        cap.grads = [(p, p.grad) for p in self.params if p.grad is not None]
+        return cap

@@ -3,8 +3,15 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I scenesplat_amd/csrc [-DFA32_ABL=m] \
 //         scripts/ubench/attn_bench.hip -o attn_bench
 // FA32_ABL bits: 1 no global loads / LDS staging writes, 2 no barrier, 4 exp -> mul, 8 no max / rescale,
-//                16 no PV MFMAs, 32 no QK^T MFMAs.   (results are wrong by construction; only the time is read)
+//                16 no PV MFMAs, 32 no QK^T MFMAs.   -DFA32_PERSIST times the rejected persistent variant,
+//                -DFA32_CLOCK reads the in-kernel clock stamps.   (results are wrong by construction; only the time is read)
 #include "../../scenesplat_amd/csrc/attention_mfma32.hip"
+#ifdef FA32_PERSIST
+#include "attn_fwd_persistent.inc"   // rejected persistent variant (see its header)
+#define FWD_LAUNCH fa32_persistent_launch
+#else
+#define FWD_LAUNCH ss_attn_fwd_mfma32
+#endif
 #include <cstdio>
 #include <cstring>
 #include <cmath>
@@ -33,14 +40,31 @@ int main(int argc, char** argv) {
   hipMemcpy(dw, win.data(), (W + 1) * 4, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const float scale = 1.f / sqrtf((float)D);
-  for (int i = 0; i < 3; ++i) ss_attn_fwd_mfma32(dq, dg, dg, dw, W, K, dout, dlse, C, H, scale, 0);
+  for (int i = 0; i < 3; ++i) FWD_LAUNCH(dq, dg, dg, dw, W, K, dout, dlse, C, H, scale, 0);
   hipDeviceSynchronize();
   const int iters = 20;
   hipEventRecord(e0, 0);
-  for (int i = 0; i < iters; ++i) ss_attn_fwd_mfma32(dq, dg, dg, dw, W, K, dout, dlse, C, H, scale, 0);
+  for (int i = 0; i < iters; ++i) FWD_LAUNCH(dq, dg, dg, dw, W, K, dout, dlse, C, H, scale, 0);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
   const double fl = (double)W * H * 4.0 * K * K * D;
   printf("attn fwd32 d=%d ABL=%d: %.3f ms  %.0f TFLOP/s (%.1f %% of 2.5 PF)\n", D, (int)FA32_ABL, ms, fl / ms / 1e9, fl / ms / 1e9 / 25.0);
+#ifdef FA32_CLOCK
+  {
+    // keep the chip loaded for ~2 s first (the clock the chip HOLDS under this kernel), then read the stamps of the last launch
+    for (int i = 0; i < 4000; ++i) FWD_LAUNCH(dq, dg, dg, dw, W, K, dout, dlse, C, H, scale, 0);
+    hipDeviceSynchronize();
+    const int nwg = std::min(32768, W * H * ((K + FA32_BQ - 1) / FA32_BQ));
+    std::vector<unsigned long long> st(4 * nwg);
+    hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(fa32_stamp), st.size() * 8);
+    std::vector<double> ghz, cyc;
+    for (int i = 0; i < nwg; ++i) {
+      double dc = (double)(st[4 * i + 2] - st[4 * i]), dr = (double)(st[4 * i + 3] - st[4 * i + 1]);
+      if (dr > 0) { ghz.push_back(dc / dr * 0.1); cyc.push_back(dc); }
+    }
+    std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
+    printf("  in-kernel clock (median over %zu workgroups): %.2f GHz; tile loop %.0f shader cycles per workgroup (16 tiles)\n", ghz.size(), ghz[ghz.size() / 2], cyc[cyc.size() / 2]);
+  }
+#endif
   return 0;
 }

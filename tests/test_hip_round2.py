@@ -382,3 +382,103 @@ def test_grouped_stage_wgrads_equal_per_layer_launches(monkeypatch):
     for k in grads["single"]:
         a, b = grads["grouped"][k], grads["single"][k]
         assert a.dtype == b.dtype and (a - b).norm() <= 2e-3 * b.norm() + 1e-7, (k, (a - b).norm() / b.norm())
+
+
+# ---- steady-state hipGraph replay (scenesplat_amd/steady_state.py) --------------------------------------------
+def _steady_setup(drop_path=0.0):
+    from scenesplat_amd.pointcept_api import MODELS
+    from scenesplat_amd.synthetic import room_chunk
+    torch.manual_seed(11)
+    model = MODELS.build(dict(type="PT-v3m1", **TINY, drop_path=drop_path, shuffle_orders=True)).cuda().train()
+    d = {k: v.cuda() for k, v in room_chunk(n_side=40, seed=3, lang_dim=0).items()}
+    n = d["feat"].shape[0]
+
+    def fn(plan, t):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(dict(feat=t["feat"], grid_coord=d["grid_coord"], offset=d["offset"], plan=plan))
+        torch.autograd.backward(out.feat, grad_tensors=t["cot"])
+        return {"feat": out.feat}
+    return model, d, n, fn
+
+
+def test_steady_state_replay_equals_the_eager_step():
+    """Captured fwd+bwd replayed with OTHER features, OTHER curve permutations (shuffle_orders) and after optimizer steps
+    equals the eager step on the same plan: output rows and every parameter gradient (fp32 atomics: 2e-3 relative)."""
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.steady_state import SteadyStateStep
+    with _Runtime(conv_dtype=torch.bfloat16, attn_impl=nv.ATTN_MFMA):
+        model, d, n, fn = _steady_setup()
+        params = list(model.parameters())
+        steady = SteadyStateStep(fn, params, warmup=1)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        for it in range(5):
+            feat = torch.randn(n, 11, device="cuda", generator=g)
+            cot = torch.randn(n, TINY["dec_channels"][0], device="cuda", generator=g).to(torch.bfloat16)
+            perms = model.draw_perms()
+            model.zero_grad(set_to_none=True)
+            ref = fn(model.prepare_plan(d, perms=perms), dict(feat=feat, cot=cot))["feat"].detach().float().clone()
+            rg = {k: p.grad.clone() for k, p in model.named_parameters()}
+            model.zero_grad(set_to_none=True)
+            out = steady(model.prepare_plan(d, perms=perms), dict(feat=feat, cot=cot))["feat"].float()
+            assert steady.refused is None, steady.refused
+            # two EAGER runs of this bf16 step already differ by ~3e-3 (fp32 atomics in the statistics, amplified through
+            # the bf16 roundings of a dozen layers); a stale index table or stale weights are O(0.1 - 1)
+            assert (out - ref).norm() <= 1e-2 * ref.norm(), (it, (out - ref).norm() / ref.norm())
+            errs = {}
+            for k, p in model.named_parameters():
+                assert p.grad is not None, k
+                errs[k] = (float((p.grad - rg[k]).norm()), float(rg[k].norm()))
+            num, den = sum(e * e for e, _ in errs.values()) ** 0.5, sum(r * r for _, r in errs.values()) ** 0.5
+            assert num <= 2e-2 * den, (it, num / den)
+            # tensor by tensor only where the gradient is not a cancelling sum of the random cotangent (bias sums of the
+            # first blocks differ by tens of percent between two EAGER runs): every tensor holding >= 2 % of the norm
+            for k, (e, r) in errs.items():
+                assert r < 0.02 * den or e <= 0.1 * r, (it, k, e / r)
+            with torch.no_grad():            # the next replay must see these weights (shadows are re-cast inside the graph)
+                for p in params:
+                    p.mul_(1.0 + 0.1 * (it % 2 * 2 - 1))
+        assert steady.eager_steps == 2 and steady.replays == 3          # warm-up step, sync-checked step, then the graph
+
+
+def test_steady_state_falls_back_to_eager_on_other_shapes_and_refused_captures():
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.steady_state import SteadyStateStep
+    from scenesplat_amd.synthetic import room_chunk
+    with _Runtime(conv_dtype=torch.bfloat16, attn_impl=nv.ATTN_MFMA):
+        model, d, n, fn = _steady_setup()
+        steady = SteadyStateStep(fn, model.parameters(), warmup=0)
+        cot = torch.randn(n, TINY["dec_channels"][0], device="cuda").to(torch.bfloat16)
+        steady(model.prepare_plan(d), dict(feat=d["feat"], cot=cot))          # the sync-checked eager step
+        steady(model.prepare_plan(d), dict(feat=d["feat"], cot=cot))
+        assert steady.replays == 1 and steady.eager_steps == 1
+        # another geometry -> another signature: its first step (warmup=0) is captured too, the first graph stays usable
+        d2 = {k: v.cuda() for k, v in room_chunk(n_side=36, seed=4, lang_dim=0).items()}
+        n2 = d2["feat"].shape[0]
+
+        def fn2(plan, t):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = model(dict(feat=t["feat"], grid_coord=d2["grid_coord"], offset=d2["offset"], plan=plan))
+            torch.autograd.backward(out.feat, grad_tensors=t["cot"])
+            return {"feat": out.feat}
+        assert model.prepare_plan(d2).signature() != model.prepare_plan(d).signature()
+        # a step that reads a value on the host cannot be captured: the exception is kept, the step runs eagerly
+        def syncing(plan, t):
+            r = fn2(plan, t)
+            float(r["feat"].detach().float().sum())
+            return r
+        bad = SteadyStateStep(syncing, model.parameters(), warmup=0)
+        cot2 = torch.randn(n2, TINY["dec_channels"][0], device="cuda").to(torch.bfloat16)
+        out = bad(model.prepare_plan(d2), dict(feat=d2["feat"], cot=cot2))["feat"]
+        assert bad.refused is not None and bad.replays == 0, bad.refused      # refused by the sync-checked eager step
+        assert torch.isfinite(out.float()).all()
+        out = bad(model.prepare_plan(d2), dict(feat=d2["feat"], cot=cot2))["feat"]        # and keeps working
+        assert bad.replays == 0 and torch.isfinite(out.float()).all()
+        # an autograd graph kept alive from an earlier step is found by the checked step as well (it would poison a capture)
+        held = fn2(model.prepare_plan(d2), dict(feat=d2["feat"], cot=cot2))["feat"]       # NOT detached: holds the graph
+        bad2 = SteadyStateStep(fn2, model.parameters(), warmup=0)
+        out = bad2(model.prepare_plan(d2), dict(feat=d2["feat"], cot=cot2))["feat"]
+        assert bad2.refused is not None and "autograd graph" in bad2.refused and bad2.replays == 0, bad2.refused
+        assert torch.isfinite(out.float()).all() and held.grad_fn is not None
+        del held
+        out = steady(model.prepare_plan(d), dict(feat=d["feat"], cot=cot))["feat"]        # the first graph is intact
+        assert steady.replays == 2 and torch.isfinite(out.float()).all()
