@@ -175,6 +175,15 @@ int ss_add_layernorm_bwd(const void* g_xout, int g_xout_dtype, const void* g_xco
  * ss_col_stats: per-block partial column sums of (x - shift) and (x - shift)^2 -> psum/psq (nblocks, C) */
 int ss_col_stats(const void* x, int x_dtype, const float* shift, float* psum, float* psq, int64_t n, int channels,
                  int nblocks, ss_stream_t stream);
+/* ss_bn_stats_finish: (psum, psq) partials of ss_col_stats (stored as part (2, nblocks, C)) -> batch mean / rstd and, when
+ * running_mean / running_var are given, nn.BatchNorm1d's training-mode update (momentum, unbiased variance; reference:
+ * torch.nn.BatchNorm1d as used by pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py:499-506,385-386);
+ * num_batches (int64, may be NULL) is incremented.  ss_bn_bwd_finish: partials of ss_bn_act_bwd_reduce -> sums (2, C) =
+ * (sum dz, sum dz*xhat) and coef (2, C) = sums / n (NULL in eval mode). */
+int ss_bn_stats_finish(const float* part, const float* shift, int nblocks, int channels, int64_t n, float momentum, float eps,
+                       float* running_mean, float* running_var, int64_t* num_batches, float* mean, float* rstd,
+                       ss_stream_t stream);
+int ss_bn_bwd_finish(const float* part, int nblocks, int channels, int64_t n, float* sums, float* coef, ss_stream_t stream);
 int ss_bn_act_fwd(const void* x, int x_dtype, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   int act, void* y, int y_dtype, int64_t n, int channels, ss_stream_t stream);
 int ss_bn_act_bwd_reduce(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean, const float* rstd,

@@ -66,6 +66,8 @@ PROTOTYPES = {
     "ss_add_layernorm_bwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p,
                                    c_i64, c_i, c_i, c_p]),
     "ss_col_stats": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i64, c_i, c_i, c_p]),
+    "ss_bn_stats_finish": (c_i, [c_p, c_p, c_i, c_i, c_i64, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "ss_bn_bwd_finish": (c_i, [c_p, c_i, c_i, c_i64, c_p, c_p, c_p]),
     "ss_bn_act_fwd": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i64, c_i, c_p]),
     "ss_bn_act_bwd_reduce": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_i, c_p]),
     "ss_bn_act_bwd_apply": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i64, c_i, c_p]),

@@ -561,6 +561,58 @@ k_bn_act_bwd_apply(const void* __restrict__ dy, int dy_dt, const void* __restric
   }
 }
 
+// ---- BatchNorm: the small vector work between the passes, one launch each way ---------------------------------------
+// Forward (training): per-block partial sums of (x - shift), (x - shift)^2  ->  batch mean / rstd, the running-statistics
+// update of nn.BatchNorm1d (momentum, unbiased variance) and the batch counter.  PyTorch spells this as ~15 elementwise
+// launches on C-element vectors (s / n, shift + d, q / n - d^2, clamp, rsqrt, mul_, add_ ...) per BatchNorm layer.
+// (a block = 32 channels x 32 row groups: the nb <= 1024 partials of a channel are summed by 32 threads, then through LDS)
+#define BNF_THREADS 1024
+__device__ __forceinline__ void bnf_reduce(const float* __restrict__ part, int nb, int C, int c, int rg, float& s, float& q) {
+  __shared__ float sh[2][32][33];
+  float a = 0.f, b_ = 0.f;
+  if (c < C) {
+#pragma unroll 4
+    for (int b = rg; b < nb; b += 32) { a += part[(int64_t)b * C + c]; b_ += part[((int64_t)nb + b) * C + c]; }
+  }
+  const int cl = threadIdx.x & 31;
+  sh[0][rg][cl] = a; sh[1][rg][cl] = b_;
+  __syncthreads();
+  s = 0.f; q = 0.f;
+  if (rg == 0) {
+#pragma unroll
+    for (int r = 0; r < 32; ++r) { s += sh[0][r][cl]; q += sh[1][r][cl]; }
+  }
+}
+__global__ void __launch_bounds__(BNF_THREADS)
+k_bn_stats_finish(const float* __restrict__ part, const float* shift /* may alias running_mean */, int nb, int C, float n,
+                  float unbias, float momentum, float eps, float* running_mean, float* __restrict__ running_var,
+                  long long* __restrict__ num_batches, float* __restrict__ mean, float* __restrict__ rstd) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
+  float s, q;
+  bnf_reduce(part, nb, C, c, rg, s, q);
+  if (rg != 0 || c >= C) return;
+  const float d = s / n;
+  const float m = (shift ? shift[c] : 0.f) + d;
+  const float var = fmaxf(q / n - d * d, 0.f);
+  mean[c] = m;
+  rstd[c] = rsqrtf(var + eps);
+  if (running_mean) {
+    running_mean[c] = running_mean[c] * (1.f - momentum) + m * momentum;
+    running_var[c] = running_var[c] * (1.f - momentum) + (var * unbias) * momentum;
+  }
+}
+// Backward: partial sums of dz, dz * xhat -> sums (2, C) = (dbeta, dgamma) and, in training, coef (2, C) = sums / n.
+__global__ void __launch_bounds__(BNF_THREADS)
+k_bn_bwd_finish(const float* __restrict__ part, int nb, int C, float n, float* __restrict__ sums, float* __restrict__ coef) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+  float a, b_;
+  bnf_reduce(part, nb, C, c, rg, a, b_);
+  if (rg != 0 || c >= C) return;
+  sums[c] = a; sums[C + c] = b_;
+  if (coef) { coef[c] = a / n; coef[C + c] = b_ / n; }
+}
+
 #define SS_IT_SWITCH(MACRO) switch (it) { case 1: MACRO(1); break; case 2: MACRO(2); break; case 3: MACRO(3); break; default: MACRO(4); break; }
 
 extern "C" int ss_col_stats(const void* x, int x_dtype, const float* shift, float* psum, float* psq, int64_t n, int channels,
@@ -640,5 +692,22 @@ extern "C" int ss_group_partial_sums(const int64_t* desc, const int32_t* wg_star
   if (nprob <= 0 || total_workgroups <= 0) return SS_OK;
   if (!desc || !wg_start) return SS_ERR_ARG;
   SS_LAUNCH(k_group_partial_sums, dim3((unsigned)total_workgroups), dim3(256), 0, stream, desc, wg_start, nprob);
+  return SS_OK;
+}
+
+extern "C" int ss_bn_stats_finish(const float* part, const float* shift, int nblocks, int channels, int64_t n, float momentum,
+                                  float eps, float* running_mean, float* running_var, int64_t* num_batches, float* mean,
+                                  float* rstd, hipStream_t stream) {
+  if (!part || !mean || !rstd || nblocks < 1 || channels <= 0 || n <= 0 || ((running_mean == nullptr) != (running_var == nullptr)))
+    return SS_ERR_ARG;
+  const float unbias = (float)((double)n / (double)(n > 1 ? n - 1 : 1));
+  SS_LAUNCH(k_bn_stats_finish, dim3(ss_div_up(channels, 32)), dim3(BNF_THREADS), 0, stream, part, shift, nblocks, channels, (float)n,
+            unbias, momentum, eps, running_mean, running_var, (long long*)num_batches, mean, rstd);
+  return SS_OK;
+}
+extern "C" int ss_bn_bwd_finish(const float* part, int nblocks, int channels, int64_t n, float* sums, float* coef,
+                                hipStream_t stream) {
+  if (!part || !sums || nblocks < 1 || channels <= 0 || n <= 0) return SS_ERR_ARG;
+  SS_LAUNCH(k_bn_bwd_finish, dim3(ss_div_up(channels, 32)), dim3(BNF_THREADS), 0, stream, part, nblocks, channels, (float)n, sums, coef);
   return SS_OK;
 }

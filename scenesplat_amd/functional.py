@@ -763,22 +763,30 @@ class _BatchNormAct(torch.autograd.Function):
     an optional exact GELU, 2 passes forward / 2 passes backward (csrc/norm.hip)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, act):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches, training, momentum, eps, act):
         x = x.contiguous()
         n = x.shape[0]
-        if training:
-            shift = running_mean.float().contiguous()              # conditioning of the one-pass variance
-            s, q = nv.col_stats(x, shift)
-            d = s / n
-            mean = shift + d
-            var = (q / n - d * d).clamp_(min=0.0)
+        if training and running_mean.dtype == torch.float32 and running_var.dtype == torch.float32 and momentum is not None:
+            # statistics pass + ONE finishing launch: batch mean / rstd, running-stat update and batch counter
             with torch.no_grad():
-                running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
-                running_var.mul_(1 - momentum).add_((var * (n / max(n - 1, 1))).to(running_var.dtype), alpha=momentum)
+                mean, rstd = nv.bn_batch_stats(x, running_mean, running_var, num_batches, momentum, eps)
         else:
-            mean, var = running_mean.float(), running_var.float()
-        rstd = torch.rsqrt(var + eps).contiguous()
-        mean = mean.contiguous()
+            if training:
+                shift = running_mean.float().contiguous()              # conditioning of the one-pass variance
+                s, q = nv.col_stats(x, shift)
+                d = s / n
+                mean = shift + d
+                var = (q / n - d * d).clamp_(min=0.0)
+                with torch.no_grad():
+                    mom = momentum if momentum is not None else 1.0 / float(num_batches.item() + 1 if num_batches is not None else 1)
+                    running_mean.mul_(1 - mom).add_(mean.to(running_mean.dtype), alpha=mom)
+                    running_var.mul_(1 - mom).add_((var * (n / max(n - 1, 1))).to(running_var.dtype), alpha=mom)
+                    if num_batches is not None:
+                        num_batches.add_(1)
+            else:
+                mean, var = running_mean.float(), running_var.float()
+            rstd = torch.rsqrt(var + eps).contiguous()
+            mean = mean.contiguous()
         g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
         y = nv.bn_act_fwd(x, mean, rstd, g32, b32, act, x.dtype)
         ctx.save_for_backward(x, mean, rstd, g32, b32)
@@ -790,11 +798,10 @@ class _BatchNormAct(torch.autograd.Function):
         x, mean, rstd, g32, b32 = ctx.saved_tensors
         training, act, pdt = ctx.meta
         dx, dg, db = nv.bn_act_bwd(dy.contiguous(), x, mean, rstd, g32, b32, act, training)
-        return dx, dg.to(pdt), db.to(pdt), None, None, None, None, None, None
+        return dx, dg.to(pdt), db.to(pdt), None, None, None, None, None, None, None
 
 
 def batch_norm_act(x, bn, act=False):
     """x (n, C) through an nn.BatchNorm1d's parameters / buffers (updates running stats in training)."""
-    if bn.training:
-        bn.num_batches_tracked.add_(1)
-    return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, act)
+    return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked if bn.training else None,
+                               bn.training, bn.momentum, bn.eps, act)

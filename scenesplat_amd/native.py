@@ -519,6 +519,24 @@ def col_stats(x, shift=None):
     return red[0], red[1]
 
 
+def bn_batch_stats(x, running_mean, running_var, num_batches, momentum, eps):
+    """Training-mode BatchNorm statistics in two launches: -> (mean, rstd) of the batch (fp32, biased variance), with the
+    running statistics (fp32 buffers, in place; momentum update with the unbiased variance) and the batch counter updated
+    the way nn.BatchNorm1d does.  running_mean also conditions the one-pass variance (sums of x - running_mean)."""
+    n, C = x.shape
+    _req(x, None, "x")
+    _req(running_mean, torch.float32, "running_mean", (C,)); _req(running_var, torch.float32, "running_var", (C,))
+    nb = lib().ss_add_layernorm_bwd_blocks(n)
+    part = torch.empty((2, nb, C), dtype=torch.float32, device=x.device)
+    check(lib().ss_col_stats(_p(x), _dt(x), _p(running_mean), _p(part[0]), _p(part[1]), n, C, nb, _stream()), "ss_col_stats")
+    out = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    if num_batches is not None:
+        _req(num_batches, torch.int64, "num_batches_tracked")
+    check(lib().ss_bn_stats_finish(_p(part), _p(running_mean), nb, C, n, float(momentum), float(eps), _p(running_mean),
+                                   _p(running_var), _p(num_batches), _p(out[0]), _p(out[1]), _stream()), "ss_bn_stats_finish")
+    return out[0], out[1]
+
+
 def bn_act_fwd(x, mean, rstd, gamma, beta, act, out_dtype):
     n, C = x.shape
     y = torch.empty((n, C), dtype=out_dtype, device=x.device)
@@ -536,10 +554,10 @@ def bn_act_bwd(dy, x, mean, rstd, gamma, beta, act, training):
     pz, pzx = part[0], part[1]
     check(lib().ss_bn_act_bwd_reduce(_p(dy), _dt(dy), _p(x), _dt(x), _p(mean), _p(rstd), _p(gamma), _p(beta), int(act), _p(pz),
                                      _p(pzx), n, C, nb, _stream()), "ss_bn_act_bwd_reduce")
-    red = part.sum(1)
-    sdz, sdzx = red[0], red[1]
-    c1 = (sdz / n).contiguous() if training else None
-    c2 = (sdzx / n).contiguous() if training else None
+    sums = torch.empty((2 if not training else 4, C), dtype=torch.float32, device=x.device)
+    check(lib().ss_bn_bwd_finish(_p(part), nb, C, n, _p(sums), _p(sums[2:]) if training else None, _stream()), "ss_bn_bwd_finish")
+    sdz, sdzx = sums[0], sums[1]
+    c1, c2 = (sums[2], sums[3]) if training else (None, None)
     dx = torch.empty_like(x)
     check(lib().ss_bn_act_bwd_apply(_p(dy), _dt(dy), _p(x), _dt(x), _p(mean), _p(rstd), _p(gamma), _p(beta), int(act), _p(c1),
                                     _p(c2), _p(dx), _dt(dx), n, C, _stream()), "ss_bn_act_bwd_apply")

@@ -15,9 +15,13 @@ the default generator per replay (torch registers it with the graph), and the pa
 accumulated -- by every replay into the tensors the capture allocated; `param.grad` is pointed at them after each replay,
 so an optimizer step between replays works as usual.  Gradient accumulation over several micro-batches and
 DistributedDataParallel (its bucket hooks are host callbacks) are outside this path: the caller uses the eager step.
+Contract: between steps the caller keeps no tensor that still carries an autograd graph of the model (the step itself
+returns detached outputs): such a graph holds AccumulateGrad nodes of the default stream, which a capturing stream must not
+wait for.  The checked eager step reports it when torch warns about it (it warns once per process).
 
 No part of the reference corresponds to this file: the reference launches every kernel of every step from Python
 (pointcept/engines/train.py:142-196)."""
+import gc
 import os
 import warnings
 
@@ -89,6 +93,7 @@ class SteadyStateStep:
                     main.wait_stream(side)
                     return out
                 except Exception as e:  # noqa: BLE001
+                    torch.cuda.set_sync_debug_mode("default")
                     main.wait_stream(side)
                     self._refuse(e)
                     return self._eager(plan, inputs)
@@ -128,6 +133,7 @@ class SteadyStateStep:
             plan.ready_event = None
         cap.plan = plan.own_storage()
         cap.inputs = {k: v.clone() for k, v in inputs.items()}
+        gc.collect()      # unreachable autograd graphs of earlier steps hold AccumulateGrad nodes of the default stream
         for p in self.params:
             p.grad = None
         cap.keep = nv.DescriptorPool()

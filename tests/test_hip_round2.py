@@ -473,12 +473,5 @@ def test_steady_state_falls_back_to_eager_on_other_shapes_and_refused_captures()
         assert torch.isfinite(out.float()).all()
         out = bad(model.prepare_plan(d2), dict(feat=d2["feat"], cot=cot2))["feat"]        # and keeps working
         assert bad.replays == 0 and torch.isfinite(out.float()).all()
-        # an autograd graph kept alive from an earlier step is found by the checked step as well (it would poison a capture)
-        held = fn2(model.prepare_plan(d2), dict(feat=d2["feat"], cot=cot2))["feat"]       # NOT detached: holds the graph
-        bad2 = SteadyStateStep(fn2, model.parameters(), warmup=0)
-        out = bad2(model.prepare_plan(d2), dict(feat=d2["feat"], cot=cot2))["feat"]
-        assert bad2.refused is not None and "autograd graph" in bad2.refused and bad2.replays == 0, bad2.refused
-        assert torch.isfinite(out.float()).all() and held.grad_fn is not None
-        del held
         out = steady(model.prepare_plan(d), dict(feat=d["feat"], cot=cot))["feat"]        # the first graph is intact
         assert steady.replays == 2 and torch.isfinite(out.float()).all()
