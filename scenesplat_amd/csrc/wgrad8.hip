@@ -356,7 +356,16 @@ static void w8_linear_plan(int64_t m, int k_in, int n_out, int* tm_, int* tn_, i
   const int tm = ss_div_up(n_out, 256), tn = ss_div_up(k_in, 256);
   static int env_per = -2;
   if (env_per == -2) { const char* e = getenv("SS_WGRAD_MINPER"); env_per = e ? atoi(e) : -1; }
-  int min_per = env_per > 0 ? env_per : (int)(((int64_t)nblocks * tm * tn + 255) / 256);
+  // shares per tile = floor(CUs / tiles): rounding the share LENGTH instead (ceil(nblocks tiles / 256)) let the workgroup
+  // count overshoot the CU count (27 tiles x 10 shares = 270, 36 x 8 = 288, 9 x 29 = 261) and every such launch ran a
+  // second, almost empty round: one workgroup per CU (128 KiB of LDS each)
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  const int shares = cus / (tm * tn) > 0 ? cus / (tm * tn) : 1;
+  int min_per = env_per > 0 ? env_per : (int)((nblocks + shares - 1) / shares);
   if (env_per <= 0 && min_per < 8) min_per = 8;
   if (min_per > nblocks) min_per = nblocks;
   *tm_ = tm; *tn_ = tn; *min_per_ = min_per; *splits_ = ss_div_up(nblocks, min_per);
