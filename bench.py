@@ -99,6 +99,30 @@ def pmc_traffic(log, timeout_s=240):
     return out
 
 
+def power_limited_peak(log):
+    """Dense bf16 MFMA rate the chip SUSTAINS with toggling operands (scripts/ubench/mfma_peak.hip, random bf16 operands, ~0.3 s):
+    the datasheet peak the `roofline` objects are priced against is reached only with constant operands; real data is
+    power-limited well below it.  Informational, measured in this run; None when the probe binary is missing."""
+    import re
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts", "ubench", "bin", "mfma_peak")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "1000000", "1"], capture_output=True, text=True, timeout=60).stdout
+        vals = [(float(a), float(b)) for a, b in re.findall(r"([0-9.]+) TFLOP/s dense bf16 .*? shader clock ([0-9.]+) GHz", out)]
+        if not vals:
+            return None
+        tf, ghz = vals[-1]
+        log("dense bf16 MFMA with random operands: %.0f TFLOP/s sustained at %.2f GHz (datasheet peak 2500)" % (tf, ghz))
+        return {"value": tf, "unit": "TFLOP/s", "shader_clock_ghz": ghz,
+                "how": "scripts/ubench/mfma_peak.hip: register-resident v_mfma_f32_32x32x16_bf16, random operands alternating between two sets, "
+                       "4 waves/SIMD, measured in this run"}
+    except Exception as e:  # noqa: BLE001
+        log("mfma_peak probe failed: %r" % (e,))
+        return None
+
+
 def roofline_lines(log, want_pmc):
     """roofline objects of the bench line: every probe timed with HIP events in THIS process, PMC traffic from child passes."""
     rp = _probes_module()
@@ -383,6 +407,12 @@ def main():
             net = model = None                                 # (cells of step(): releases the model and its plan)
             gc.collect(); torch.cuda.empty_cache()
             rl = roofline_lines(log, not args.no_pmc)
+            plp = power_limited_peak(log)
+            for ent in rl.values():
+                if ent.get("bound") == "mfma" and plp:
+                    ent["power_limited_peak"] = plp["value"]
+                    ent["frac_of_power_limited_peak"] = ent["achieved"] / plp["value"]
+            res["power_limited_mfma_peak"] = plp
             res["roofline"] = rl["conv_fwd"]                  # the dominant kernel of the step
             res["roofline_conv_wgrad"] = rl["conv_wgrad"]
             res["roofline_attn"] = rl["attn_fwd"]             # the kernel the north star names

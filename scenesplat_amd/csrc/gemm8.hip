@@ -31,6 +31,9 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 g8_bf8_t;
 #define G8_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 #define G8_TAPS_MAX 27
+#ifndef G8_KCHUNK_DEFAULT
+#define G8_KCHUNK_DEFAULT 0      // channels per K-walk chunk of the conv (0 = whole rows); see g8_launch
+#endif
 #define G8_ZERO_ELEMS 4096
 
 #ifndef G8_STAGGER
@@ -58,7 +61,7 @@ template <bool GATHER, typename OutT>
 __global__ void __launch_bounds__(512)
 k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, const float* __restrict__ bias,
         const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowperm, OutT* __restrict__ out, int M, int K,
-        int N, int taps, int ntn, int tap_inner) {
+        int N, int taps, int ntn, int kchunk) {
   __shared__ __attribute__((aligned(16))) char smem[G8_LDS_BYTES];   // ONE object: tiles + rulebook slice
   int32_t* nbr_s = reinterpret_cast<int32_t*>(smem + G8_OFF_NBR);
   int32_t* rowid_s = reinterpret_cast<int32_t*>(smem + G8_OFF_ROWID);
@@ -139,29 +142,28 @@ k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__
       pB[h][j] = W + (int64_t)col * taps * K + lc8;
     }
   int kc = 0;                                    // channel offset of the tile being staged
+  int kbase = 0, kend = GATHER ? min(kchunk, K) : K;   // current channel chunk (GATHER)
   int64_t boff = (int64_t)tap * K;               // tap offset in W rows
   load_rows(tap);
   int staged = 0;                                // index of the tile the state describes
   auto advance = [&]() {
     if (staged + 1 >= T) return;                 // past the end: keep re-staging the last tile (harmless, keeps vmcnt uniform)
     ++staged;
-    if (GATHER && tap_inner) {
-      // experiment (off by default, see g8_launch): channel chunk outer, tap inner -- the 64-channel pieces of the tile's
-      // rows are fetched for all active taps back to back so that re-reads hit the XCD's L2
-      if (rem == 0u) { kc += 64; rem = mask_all; }
-      tap = __builtin_ctz(rem); rem &= rem - 1u;
-      boff = (int64_t)tap * K;
-      load_rows(tap);
-      return;
-    }
     kc += 64;
-    if (kc == K) {
-      kc = 0;
-      if (GATHER) {
+    if (GATHER) {
+      // K walk of the conv: channel chunks of `kchunk` (a multiple of 64; kchunk >= K: one chunk) outermost, the tile's
+      // active taps inside a chunk, 64-channel K-tiles innermost.  With one chunk the rows of a tap are streamed whole
+      // (1.5 KB per site and tap: ~4 MB per tap step over the tiles an XCD runs -- the next tap's re-reads of the same rows
+      // miss its L2); a smaller chunk keeps the pieces of the tile's rows L2-resident across the taps.
+      if (kc == kend) {
+        if (rem == 0u) { kbase = kend; kend = min(kbase + kchunk, K); rem = mask_all; }
+        kc = kbase;
         tap = __builtin_ctz(rem); rem &= rem - 1u;
         boff = (int64_t)tap * K;
         load_rows(tap);
       }
+    } else if (kc == K) {
+      kc = 0;
     }
   };
   char* const dst0 = smem + wave * 1024;
@@ -294,17 +296,19 @@ template <bool GATHER>
 static int g8_launch(const void* a, const void* w, const float* bias, const int32_t* nbr, const int32_t* rowperm, void* out,
                      int64_t m, int k, int n, int taps, int out_dtype, hipStream_t stream) {
   if (!ss_gemm8_ok(m, k, n, taps)) return SS_ERR_ARG;
-  // SS_CONV_TAP_INNER=1 (diagnostic A/B switch, read once): channel-chunk-outer / tap-inner K walk.  Measured SLOWER at
-  // dec0 (1.03 -> 1.24 ms) and dec1 (0.23 -> 0.28 ms): the per-K-tile address rebuild and the scattered 128-byte row
-  // pieces cost more than the L2 re-use of the rows buys; the default stays tap-outer (rows streamed 1.5 KB at a time)
-  static const int tap_inner = [] { const char* e = getenv("SS_CONV_TAP_INNER"); return e ? atoi(e) : 0; }();
+  // SS_CONV_KCHUNK (diagnostic A/B switch, read once): channels per chunk of the conv's K walk, a multiple of 64; 0 = the
+  // whole row per tap.  (64 = the round-2 "tap inner" experiment.)
+  static const int kchunk_env = [] { const char* e = getenv("SS_CONV_KCHUNK"); return e ? atoi(e) : -1; }();
+  int kchunk = kchunk_env >= 0 ? kchunk_env : G8_KCHUNK_DEFAULT;
+  if (kchunk <= 0 || kchunk > k) kchunk = k;
+  kchunk = (kchunk + 63) & ~63;
   const int ntm = ss_div_up(m, 256), ntn = ss_div_up(n, 256);
   dim3 grid(ntm * ntn), block(512);
   const unsigned short* A = (const unsigned short*)a; const unsigned short* Wp = (const unsigned short*)w;
   if (out_dtype == SS_BF16)
-    SS_LAUNCH((k_gemm8<GATHER, unsigned short>), grid, block, 0, stream, A, Wp, bias, nbr, rowperm, (unsigned short*)out, (int)m, k, n, taps, ntn, tap_inner);
+    SS_LAUNCH((k_gemm8<GATHER, unsigned short>), grid, block, 0, stream, A, Wp, bias, nbr, rowperm, (unsigned short*)out, (int)m, k, n, taps, ntn, kchunk);
   else if (out_dtype == SS_F32)
-    SS_LAUNCH((k_gemm8<GATHER, float>), grid, block, 0, stream, A, Wp, bias, nbr, rowperm, (float*)out, (int)m, k, n, taps, ntn, tap_inner);
+    SS_LAUNCH((k_gemm8<GATHER, float>), grid, block, 0, stream, A, Wp, bias, nbr, rowperm, (float*)out, (int)m, k, n, taps, ntn, kchunk);
   else
     return SS_ERR_ARG;
   return SS_OK;

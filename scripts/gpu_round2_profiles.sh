@@ -19,9 +19,42 @@ print("\n## Roofline kernels in this trace (per launch shape)\n\n| kernel | grid
 for (k, g), v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:14]:
     print(f"| `{k}` | {g} | {len(v)} | {sum(v)/len(v):.1f} ({min(v):.1f}, {max(v):.1f}) |")
 PY
+# host launch calls per timed step: HIP API trace of a 10-step and a 50-step run, differenced (graph replay vs eager launches)
+for mode in on off; do
+  for st in 10 50; do
+    rocprofv3 --hip-trace --stats --output-format csv -d $O/hip_${mode}_$st -- python bench.py --steps $st --warmup 3 --graph $mode --no-pmc --no-secondary --no-cpu-baseline > $O/hip_${mode}_$st.log 2>&1
+  done
+done
+python - <<'PY' > gpurun_out/r2p/r02_host_launches.md
+import csv, glob, re
+def counts(d):
+    f = glob.glob(d + "/*/*hip_api_stats.csv") or glob.glob(d + "/*/*_hip_stats.csv") or glob.glob(d + "/*/*hip*stats*.csv")
+    out = {}
+    for r in csv.DictReader(open(f[0])):
+        out[r["Name"]] = int(r["Calls"])
+    return out
+def ms(log):
+    m = re.search(r"timed \d+ steps: ([0-9.]+) ms/step \(host enqueue ([0-9.]+)", open(log).read())
+    return m.groups() if m else ("?", "?")
+print("# Host-side HIP API calls per timed step (rocprofv3 --hip-trace --stats; 50-step run minus 10-step run, / 40)\n")
+print("The profiler serialises the process, so the ms/step under it are not the metric; the call counts are exact.\n")
+for mode, name in (("on", "hipGraph replay (bench default at N=1)"), ("off", "eager launches (--graph off; the N>1 path)")):
+    a, b = counts("gpurun_out/r2p/hip_%s_10" % mode), counts("gpurun_out/r2p/hip_%s_50" % mode)
+    per = {k: (b.get(k, 0) - a.get(k, 0)) / 40.0 for k in b}
+    tot = sum(v for k, v in per.items() if re.search(r"Launch|Memcpy|Memset", k))
+    print("## %s\n" % name)
+    print("launch-type calls (kernel launches, graph launches, async copies / memsets) per step: **%.0f**\n" % tot)
+    print("| calls/step | API |\n|---|---|")
+    for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:14]:
+        if v >= 0.5:
+            print("| %.1f | `%s` |" % (v, k))
+    print()
+PY
+rm -rf $O/hip_on_10 $O/hip_on_50 $O/hip_off_10 $O/hip_off_50      # (traces are large: gpurun merges back at most 64 MiB)
 rm -rf gpurun_out/pmc_sq
 bash scripts/gpu_pmc_sq.sh attn > $O/pmc_sq.log 2>&1
 python scripts/summarize_pmc.py gpurun_out/pmc_sq k_attn > $O/r02_sq_attn.txt 2>&1
+rm -rf $O/stats gpurun_out/pmc_sq
 python bench.py > $O/r02_bench_1gpu.json 2> $O/bench.err
 tail -3 $O/bench.err
 head -c 400 $O/r02_bench_1gpu.json

@@ -133,3 +133,22 @@ def test_ddp_world_size_2_gloo_matches_single_process_average():
                 tr.optimizer.step(); tr.scheduler.step()
         for k, v in tr.model.state_dict().items():
             assert torch.allclose(torch.as_tensor(res[0][1][k]), v, atol=1e-6), k
+
+
+def test_steady_state_step_disabled_is_the_plain_callable():
+    """SteadyStateStep with enabled=False (what bench.py uses under DDP): every call runs fn eagerly and hands back detached
+    outputs; nothing touches the GPU."""
+    from scenesplat_amd.steady_state import SteadyStateStep
+    w = torch.nn.Parameter(torch.ones(3))
+    calls = []
+
+    def fn(plan, t):
+        calls.append(plan)
+        y = (w * t["x"]).sum()
+        y.backward()
+        return {"y": y}
+    step = SteadyStateStep(fn, [w], enabled=False)
+    out = step("plan-a", {"x": torch.arange(3.0)})
+    assert calls == ["plan-a"] and step.eager_steps == 1 and step.replays == 0
+    assert out["y"].grad_fn is None and float(out["y"]) == 3.0
+    assert torch.equal(w.grad, torch.arange(3.0))

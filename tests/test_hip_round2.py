@@ -475,3 +475,22 @@ def test_steady_state_falls_back_to_eager_on_other_shapes_and_refused_captures()
         assert bad.replays == 0 and torch.isfinite(out.float()).all()
         out = steady(model.prepare_plan(d), dict(feat=d["feat"], cot=cot))["feat"]        # the first graph is intact
         assert steady.replays == 2 and torch.isfinite(out.float()).all()
+
+
+def test_steady_state_replays_draw_fresh_droppath_masks():
+    """DropPath inside a replayed graph: the Philox offset of the default generator advances per replay (torch registers
+    the generator with the capture), so two replays on the SAME inputs differ -- and equal inputs with drop_path = 0 do not."""
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.steady_state import SteadyStateStep
+    with _Runtime(conv_dtype=torch.bfloat16, attn_impl=nv.ATTN_MFMA):
+        for dp, differs in ((0.3, True), (0.0, False)):
+            model, d, n, fn = _steady_setup(drop_path=dp)
+            steady = SteadyStateStep(fn, model.parameters(), warmup=0)
+            cot = torch.randn(n, TINY["dec_channels"][0], device="cuda").to(torch.bfloat16)
+            perms = model.draw_perms()
+            outs = []
+            for _ in range(4):
+                outs.append(steady(model.prepare_plan(d, perms=perms), dict(feat=d["feat"], cot=cot))["feat"].float().clone())
+            assert steady.replays == 3 and steady.refused is None, steady.refused
+            rel = float((outs[2] - outs[3]).norm() / outs[3].norm())
+            assert (rel > 0.05) if differs else (rel < 1e-2), (dp, rel)
