@@ -79,7 +79,7 @@ def build(n_side=256, which=None):
         probes.append(dict(name="gather_hbm", kernel="k_gather_rows", run=lambda: nv.gather_rows(src, idx, out=dst), bound="hbm",
                            bytes=nb * (2 * C * 2 + 4), note="gather_rows(%d x %d bf16, random permutation; %.2f GB working set)" % (nb, C, 2 * nb * C * 2 / 1e9)))
     if want("scan"):
-        n, cls = 1_000_000, 160
+        n, cls = 1_000_000, int(os.environ.get("SS_PROBE_SCAN_CLASSES", "160"))     # (env: diagnostic only)
         feat = torch.nn.functional.normalize(torch.randn(n, C, device="cuda", generator=g), dim=1).to(torch.bfloat16)
         text = torch.nn.functional.normalize(torch.randn(cls, C, device="cuda", generator=g), dim=1).to(torch.bfloat16)
         probes.append(dict(name="scan", kernel="k_feat_text_scan", run=lambda: nv.feat_text_scan(feat, text), bound="hbm",
