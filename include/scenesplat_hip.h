@@ -133,6 +133,10 @@ int ss_linear_wgrad(const void* x, const void* dy, float* dweight, float* dbias,
  * ss_linear_wgrad_group_plan}; wg_start (nprob + 1) int32 device = running total of the workgroup counts that
  * ss_linear_wgrad_group_plan returns (host call, no launch; 0 = shape not eligible); every dweight / dbias zeroed. */
 int ss_linear_wgrad_group_plan(int64_t m, int k_in, int n_out, int64_t* desc_words);
+/* ..._plan2: the same with launch_tiles = sum over the launch's problems of ss_linear_wgrad_tiles(k_in, n_out) (256 x 256 output
+ * tiles): the K dimension of every problem is split so that the whole GROUP is one round of workgroups (one per CU). */
+int ss_linear_wgrad_tiles(int k_in, int n_out);
+int ss_linear_wgrad_group_plan2(int64_t m, int k_in, int n_out, int launch_tiles, int64_t* desc_words);
 int ss_linear_wgrad_group(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups, ss_stream_t stream);
 /* small levels: split-K over tap ranges; acc32 (n,cout) f32 zeroed by the caller, receives out (+bias) */
 int ss_subm_conv_splits(int64_t n, int cout, int taps);

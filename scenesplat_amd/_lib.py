@@ -55,6 +55,8 @@ PROTOTYPES = {
     "ss_subm_conv_wgrad_pipe": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "ss_linear_wgrad": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p]),
     "ss_linear_wgrad_group_plan": (c_i, [c_i64, c_i, c_i, c_p]),
+    "ss_linear_wgrad_tiles": (c_i, [c_i, c_i]),
+    "ss_linear_wgrad_group_plan2": (c_i, [c_i64, c_i, c_i, c_i, c_p]),
     "ss_linear_wgrad_group": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "ss_subm_conv_splits": (c_i, [c_i64, c_i, c_i]),
     "ss_subm_conv_fwd_splitk": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p]),

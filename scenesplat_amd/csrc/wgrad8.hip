@@ -351,7 +351,7 @@ extern "C" int ss_subm_conv_wgrad_pipe(const void* in, const void* dout, const i
 // share sizing of one nn.Linear weight gradient: every block is active here, so the shares are exact: one round of
 // <= 256 workgroups (one per CU), shares of at least 8 K-tiles (270 workgroups on 256 CUs ran two rounds: qkv 768->2304
 // took 622 us, 243 workgroups 440 us)
-static void w8_linear_plan(int64_t m, int k_in, int n_out, int* tm_, int* tn_, int* min_per_, int* splits_) {
+static void w8_linear_plan(int64_t m, int k_in, int n_out, int* tm_, int* tn_, int* min_per_, int* splits_, int launch_tiles = 0) {
   const int nblocks = ss_div_up(m, 64);
   const int tm = ss_div_up(n_out, 256), tn = ss_div_up(k_in, 256);
   static int env_per = -2;
@@ -364,7 +364,9 @@ static void w8_linear_plan(int64_t m, int k_in, int n_out, int* tm_, int* tn_, i
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n > 0 ? n : 256;
   }();
-  const int shares = cus / (tm * tn) > 0 ? cus / (tm * tn) : 1;
+  // launch_tiles: output tiles of ALL problems of a grouped launch (0: this problem is the whole launch) -- the CUs are shared out over them
+  const int tiles_all = launch_tiles > tm * tn ? launch_tiles : tm * tn;
+  const int shares = cus / tiles_all > 0 ? cus / tiles_all : 1;
   int min_per = env_per > 0 ? env_per : (int)((nblocks + shares - 1) / shares);
   if (env_per <= 0 && min_per < 8) min_per = 8;
   if (min_per > nblocks) min_per = nblocks;
@@ -373,14 +375,20 @@ static void w8_linear_plan(int64_t m, int k_in, int n_out, int* tm_, int* tn_, i
 
 // Host half of the grouped launch: fills desc words 5..7 of one problem (words 0..4 = x, dy, dW, dbias, m are the
 // caller's) and returns the number of workgroups the problem takes (0 = not eligible).
-extern "C" int ss_linear_wgrad_group_plan(int64_t m, int k_in, int n_out, int64_t* desc_words) {
+extern "C" int ss_linear_wgrad_tiles(int k_in, int n_out) { return ss_div_up(n_out, 256) * ss_div_up(k_in, 256); }
+// launch_tiles = sum of ss_linear_wgrad_tiles over the problems of the launch: one round of <= CUs workgroups for the GROUP (planning every
+// problem as if it had the chip to itself gave ten problems 240 workgroups each, 20-K-tile shares and 630 MB of fp32 atomics per launch)
+extern "C" int ss_linear_wgrad_group_plan2(int64_t m, int k_in, int n_out, int launch_tiles, int64_t* desc_words) {
   if (m <= 0 || !ss_wgrad8_ok(m, k_in, n_out, 1) || !desc_words) return 0;
   int tm, tn, min_per, splits;
-  w8_linear_plan(m, k_in, n_out, &tm, &tn, &min_per, &splits);
+  w8_linear_plan(m, k_in, n_out, &tm, &tn, &min_per, &splits, launch_tiles);
   desc_words[5] = (int64_t)((uint64_t)(uint32_t)k_in | ((uint64_t)(uint32_t)n_out << 32));
   desc_words[6] = (int64_t)((uint64_t)(uint32_t)tn | ((uint64_t)(uint32_t)(tm * tn) << 32));
   desc_words[7] = (int64_t)((uint64_t)(uint32_t)splits | ((uint64_t)(uint32_t)min_per << 32));
   return splits * tm * tn;
+}
+extern "C" int ss_linear_wgrad_group_plan(int64_t m, int k_in, int n_out, int64_t* desc_words) {
+  return ss_linear_wgrad_group_plan2(m, k_in, n_out, 0, desc_words);
 }
 
 // desc (nprob, 8) int64 and wg_start (nprob + 1) int32 in DEVICE memory (see k_wgrad8_group); every dW / dbias zeroed.

@@ -4,6 +4,7 @@ PyTorch supplies device memory and the current HIP stream only; every call here 
 hand-written HIP kernel.  Operands are validated on the host (device, dtype, contiguity,
 shape) before any launch; a CPU tensor is an error -- there is no fallback path."""
 import ctypes
+import os
 
 import torch
 
@@ -16,6 +17,7 @@ HAVE_MFMA_ATTN = True  # bf16 MFMA window attention (csrc/attention_mfma.hip)
 ORDER_IDS = {"z": 0, "z-trans": 1, "hilbert": 2, "hilbert-trans": 3}
 
 
+_GROUP_WIDE_SHARES = os.environ.get("SS_WGRAD_GROUP_WIDE", "1") != "0"   # 0: plan every problem of a group as if it had the chip to itself (diagnostic A/B)
 _GROUP_KEEP = []      # descriptor tensors of the last grouped launches (kept alive until the copies have certainly run)
 
 
@@ -367,13 +369,15 @@ def linear_wgrad_group(items):
     desc = np.zeros((len(items), 8), dtype=np.int64)
     starts = [0]
     rows = []
+    # the CUs are shared out over the output tiles of the whole group (one round of workgroups for the launch)
+    launch_tiles = sum(lib().ss_linear_wgrad_tiles(x.shape[1], dy.shape[1]) for x, dy, _, _ in items) if _GROUP_WIDE_SHARES else 0
     for x, dy, dw, db in items:
         _req(x, torch.bfloat16, "x"); _req(dy, torch.bfloat16, "dy", (x.shape[0], dy.shape[1]))
         _req(dw, torch.float32, "dw", (dy.shape[1], x.shape[1]))
         if db is not None:
             _req(db, torch.float32, "db", (dy.shape[1],))
         j = len(rows)
-        nwg = lib().ss_linear_wgrad_group_plan(x.shape[0], x.shape[1], dy.shape[1], ctypes.c_void_p(desc[j].ctypes.data))
+        nwg = lib().ss_linear_wgrad_group_plan2(x.shape[0], x.shape[1], dy.shape[1], launch_tiles, ctypes.c_void_p(desc[j].ctypes.data))
         if nwg <= 0 or len(rows) >= 128:
             linear_wgrad_into(x, dy, dw, db)
             continue
