@@ -169,6 +169,11 @@ int ss_add_layernorm_bwd_blocks(int64_t n);
  * {part (K, nb, C) f32, dst (K*C) f32, nb, C | (K*C) << 32}; wg_start (nprob + 1) int32 device, problem p owns
  * ceil(K*C / 256) workgroups; dst[k*C + c] = sum_b part[k][b][c]. */
 int ss_group_partial_sums(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups, ss_stream_t stream);
+/* ss_transpose16_group: dst (cols, rows) = src (rows, cols)^T of 2-byte elements for many matrices in one launch (transposed bf16 copies of
+ * nn.Linear weights: hipBLASLt's NT form of the dgrad GEMM dx = dy @ W, reference call site torch.nn.functional.linear backward under
+ * point_transformer_v3m1_base.py:225-248).  desc (nprob, 4) int64 device = {src, dst, rows, cols}; wg_start (nprob + 1) int32 device =
+ * running total of ceil(rows / 64) * ceil(cols / 64). */
+int ss_transpose16_group(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups, ss_stream_t stream);
 /* g_v = g_xout + g_xcopy + LN'(g_h); g_x = g_v; g_y = rowscale*g_v; dgamma/dbeta partials (nblocks, C) */
 int ss_add_layernorm_bwd(const void* g_xout, int g_xout_dtype, const void* g_xcopy, int g_xcopy_dtype, const void* g_h,
                          int g_h_dtype, const void* v, int v_dtype, const float* mean, const float* rstd,

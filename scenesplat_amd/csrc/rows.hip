@@ -260,3 +260,41 @@ extern "C" int ss_gather_add_rows(const void* a, const void* b, const int32_t* i
   SS_CHECK_LAUNCH();
   return SS_OK;
 }
+
+// ---- grouped 2-byte transpose: dst (cols, rows) = src (rows, cols)^T for many matrices in ONE launch -----------------------------------
+// The dgrad GEMM of nn.Linear, dx = dy @ W, runs 12-17 % faster on hipBLASLt when W arrives as a transposed contiguous copy (its NT
+// form; NN 0.41 / 0.45 / 0.50 ms vs NT 0.36 / 0.37 / 0.42 ms at the dec0 shapes, bit-identical results).  The copies are refreshed
+// together with the bf16 parameter shadows, all matrices of a model in this one launch.
+// desc: 4 int64 words per problem = {src, dst, rows, cols}; wg_start (nprob + 1): first workgroup; a workgroup owns one 64 x 64 tile.
+__global__ void __launch_bounds__(256)
+k_transpose16_group(const int64_t* __restrict__ desc, const int32_t* __restrict__ wg_start, int nprob) {
+  __shared__ unsigned short tile[64][66];
+  const int b = blockIdx.x;
+  int p = 0;
+  while (p + 1 < nprob && wg_start[p + 1] <= b) ++p;
+  const int64_t* d = desc + (int64_t)p * 4;
+  const unsigned short* src = reinterpret_cast<const unsigned short*>(d[0]);
+  unsigned short* dst = reinterpret_cast<unsigned short*>(d[1]);
+  const int rows = (int)d[2], cols = (int)d[3];
+  const int tc = (cols + 63) >> 6, t = b - wg_start[p];
+  const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + 4 * i, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + 4 * i][tx] = src[(int64_t)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, r = r0 + tx;
+    if (r < rows && c < cols) dst[(int64_t)c * rows + r] = tile[tx][ty + 4 * i];
+  }
+}
+
+extern "C" int ss_transpose16_group(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups, hipStream_t stream) {
+  if (nprob <= 0 || total_workgroups <= 0) return SS_OK;
+  if (!desc || !wg_start) return SS_ERR_ARG;
+  SS_LAUNCH(k_transpose16_group, dim3((unsigned)total_workgroups), dim3(256), 0, stream, desc, wg_start, nprob);
+  return SS_OK;
+}

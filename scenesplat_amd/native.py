@@ -463,6 +463,24 @@ def group_partial_sums(items):
     check(lib().ss_group_partial_sums(_p(d_dev), _p(s_dev), len(items), starts[-1], _stream()), "ss_group_partial_sums")
 
 
+def transpose16_group(pairs):
+    """ONE launch: dst (cols, rows) = src (rows, cols)^T for every (src, dst) pair of 2-byte tensors (bf16 weight copies)."""
+    import numpy as np
+    if not pairs:
+        return
+    dev = pairs[0][0].device
+    desc = np.zeros((len(pairs), 4), dtype=np.int64)
+    starts = [0]
+    for j, (src, dst) in enumerate(pairs):
+        r, c = src.shape
+        if src.element_size() != 2 or dst.element_size() != 2 or tuple(dst.shape) != (c, r) or not (src.is_contiguous() and dst.is_contiguous()):
+            raise RuntimeError("transpose16_group: contiguous 2-byte (rows, cols) -> (cols, rows) pairs")
+        desc[j] = (src.data_ptr(), dst.data_ptr(), r, c)
+        starts.append(starts[-1] + ((r + 63) // 64) * ((c + 63) // 64))
+    d_dev, s_dev = _upload_descriptors(desc, starts, dev)
+    check(lib().ss_transpose16_group(_p(d_dev), _p(s_dev), len(pairs), starts[-1], _stream()), "ss_transpose16_group")
+
+
 def ln_add_ln_bwd(g_xout, g_h, xout, t, stats, gamma0, gamma1, gx_dtype, gt_dtype, reduce=True):
     """-> (g_x, g_t, dgamma0, dbeta0, dgamma1, dbeta1); reduce=False: (g_x, g_t, part (4, nb, C)) for a grouped reduction"""
     n, C = xout.shape

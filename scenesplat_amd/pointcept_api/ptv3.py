@@ -395,6 +395,13 @@ class PointTransformerV3(PointModule):
                 elif isinstance(m, SubMConv3d):
                     params.append(m.weight)
             src, dst = SF.register_shadows(params)
+            # wide Linear layers of the two finest levels: a transposed copy for the NT form of their dgrad GEMM
+            wide = []
+            for st in [getattr(self.enc, f"enc{s}", None) for s in (0, 1)] + [getattr(getattr(self, "dec", None), f"dec{s}", None) for s in (0, 1)]:
+                if st is not None:
+                    wide += [m.weight for m in st.modules() if isinstance(m, nn.Linear) and m.weight.numel() >= 65536]
+            if RUNTIME.get("dgrad_nt", True):
+                SF.register_transposed(wide)
             # fp32 accumulators of the weight / bias gradients: one zero-filled arena per step
             total = sum(((p.numel() + 3) & ~3) for p in params if p is not None) + 4 * len(params)
             ps = (src, dst, next(self.parameters()).device, total)

@@ -494,3 +494,44 @@ def test_steady_state_replays_draw_fresh_droppath_masks():
             assert steady.replays == 3 and steady.refused is None, steady.refused
             rel = float((outs[2] - outs[3]).norm() / outs[3].norm())
             assert (rel > 0.05) if differs else (rel < 1e-2), (dp, rel)
+
+
+def test_transposed_weight_copies_feed_the_linear_dgrad():
+    """ss_transpose16_group against torch, and nn.Linear's input gradient through the (in, out) copy (hipBLASLt NT form) against the plain
+    NN form, including a refresh after the weights changed."""
+    from scenesplat_amd import functional as SF
+    from scenesplat_amd import native as nv
+    g = torch.Generator(device="cuda").manual_seed(3)
+    mats = [torch.randn(r, c, device="cuda", generator=g).to(torch.bfloat16) for r, c in ((768, 2304), (65, 130), (1, 64), (512, 512))]
+    outs = [torch.empty(m.shape[1], m.shape[0], dtype=torch.bfloat16, device="cuda") for m in mats]
+    nv.transpose16_group(list(zip(mats, outs)))
+    for m, o in zip(mats, outs):
+        assert torch.equal(o, m.t().contiguous())
+    lin = torch.nn.Linear(256, 512).cuda()
+    x = torch.randn(4096, 256, device="cuda", generator=g)
+    cot = torch.randn(4096, 512, device="cuda", generator=g).to(torch.bfloat16)
+
+    def run():
+        xin = x.clone().requires_grad_(True)
+        lin.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = SF.linear(xin, lin.weight, lin.bias)
+        y.backward(cot)
+        return y.detach().float(), xin.grad.float(), lin.weight.grad.float().clone()
+    src, dst = SF.register_shadows([lin.weight, lin.bias])
+    SF.refresh_shadows(src, dst)
+    y0, dx0, dw0 = run()                                       # NN form
+    assert SF.bf16_t_of(lin.weight) is None
+    SF.register_transposed([lin.weight])
+    SF.refresh_shadows(src, dst)
+    wt = SF.bf16_t_of(lin.weight)
+    assert wt is not None and torch.equal(wt, lin.weight.detach().to(torch.bfloat16).t().contiguous())
+    y1, dx1, dw1 = run()                                       # NT form
+    assert torch.equal(y0, y1) and (dx1 - dx0).norm() <= 1e-3 * dx0.norm() and (dw1 - dw0).norm() <= 2e-3 * dw0.norm()
+    with torch.no_grad():
+        lin.weight.mul_(1.5)
+    assert SF.bf16_t_of(lin.weight) is None                    # stale until refreshed: the caller falls back to the NN form
+    SF.refresh_shadows(src, dst)
+    assert torch.equal(SF.bf16_t_of(lin.weight), lin.weight.detach().to(torch.bfloat16).t().contiguous())
+    _, dx2, _ = run()
+    assert (dx2 - 1.5 * dx0).norm() <= 1e-2 * (1.5 * dx0).norm()
