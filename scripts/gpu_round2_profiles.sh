@@ -28,11 +28,14 @@ done
 python - <<'PY' > gpurun_out/r2p/r02_host_launches.md
 import csv, glob, re
 def counts(d):
-    f = glob.glob(d + "/*/*hip_api_stats.csv") or glob.glob(d + "/*/*_hip_stats.csv") or glob.glob(d + "/*/*hip*stats*.csv")
-    out = {}
-    for r in csv.DictReader(open(f[0])):
-        out[r["Name"]] = int(r["Calls"])
-    return out
+    best = {}
+    for f in glob.glob(d + "/*/*hip_api_stats.csv") or glob.glob(d + "/*/*_hip_stats.csv") or glob.glob(d + "/*/*hip*stats*.csv"):
+        out = {}
+        for r in csv.DictReader(open(f)):
+            out[r["Name"]] = int(r["Calls"])
+        if sum(out.values()) > sum(best.values()):      # the python process (bench.py also starts the small mfma_peak probe)
+            best = out
+    return best
 def ms(log):
     m = re.search(r"timed \d+ steps: ([0-9.]+) ms/step \(host enqueue ([0-9.]+)", open(log).read())
     return m.groups() if m else ("?", "?")
