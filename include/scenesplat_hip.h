@@ -174,6 +174,9 @@ int ss_group_partial_sums(const int64_t* desc, const int32_t* wg_start, int npro
  * point_transformer_v3m1_base.py:225-248).  desc (nprob, 4) int64 device = {src, dst, rows, cols}; wg_start (nprob + 1) int32 device =
  * running total of ceil(rows / 64) * ceil(cols / 64). */
 int ss_transpose16_group(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups, ss_stream_t stream);
+/* ss_subm_weight_mirror_group: ss_subm_weight_mirror for many conv weights in one launch; desc (nprob, 5) int64 device = {w, wt, cout, taps,
+ * cin}, wg_start = running total of taps * ceil(cout / 32) * ceil(cin / 32). */
+int ss_subm_weight_mirror_group(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups, ss_stream_t stream);
 /* g_v = g_xout + g_xcopy + LN'(g_h); g_x = g_v; g_y = rowscale*g_v; dgamma/dbeta partials (nblocks, C) */
 int ss_add_layernorm_bwd(const void* g_xout, int g_xout_dtype, const void* g_xcopy, int g_xcopy_dtype, const void* g_h,
                          int g_h_dtype, const void* v, int v_dtype, const float* mean, const float* rstd,

@@ -66,6 +66,7 @@ PROTOTYPES = {
     "ss_add_layernorm_bwd_blocks": (c_i, [c_i64]),
     "ss_group_partial_sums": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "ss_transpose16_group": (c_i, [c_p, c_p, c_i, c_i, c_p]),
+    "ss_subm_weight_mirror_group": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "ss_add_layernorm_bwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p,
                                    c_i64, c_i, c_i, c_p]),
     "ss_col_stats": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i64, c_i, c_i, c_p]),

@@ -167,6 +167,7 @@ class _SubMConv3dFused(torch.autograd.Function):
         x, w = x.contiguous(), w.contiguous()
         ctx.meta = (feat.dtype, weight.dtype, weight.shape, cin, bias is not None)
         ctx.blocks_fn, ctx.has_dup = blocks_fn, has_dup
+        ctx.wt = mirrored_of(weight) if not pad else None      # dgrad weight kept beside the shadow (functional.register_mirrored)
         ctx.im2col = (n <= CONV_IM2COL_MAX_SITES) and not has_dup
         # bf16 out under autocast (the next op is a bf16 GEMM); outside autocast (the evaluator's call form) the output
         # keeps the input's dtype so that the fp32 Linear that follows sees what the reference's fp32 conv would hand it
@@ -192,7 +193,7 @@ class _SubMConv3dFused(torch.autograd.Function):
             cols = x                                               # saved im2col(x): (n, taps * cin_padded)
             taps = nbr.shape[0]
             if ctx.needs_input_grad[0]:
-                wt = nv.subm_weight_mirror(w)                          # [ci][t'][co] = w[co][T-1-t'][ci]
+                wt = ctx.wt if ctx.wt is not None else nv.subm_weight_mirror(w)   # [ci][t'][co] = w[co][T-1-t'][ci]
                 dx = torch.nn.functional.linear(nv.subm_im2col(g, nbr), wt.view(wt.shape[0], -1))[:, :cin].to(in_dtype)
             if ctx.needs_input_grad[1]:
                 dw = _mm_f32(g.t(), cols).view(w.shape)[:, :, :cin].reshape(w_shape).to(w_dtype)
@@ -200,7 +201,7 @@ class _SubMConv3dFused(torch.autograd.Function):
                 db = g.sum(0, dtype=torch.float32).to(w_dtype)
             return dx, dw, db, None, None, None, None
         if ctx.needs_input_grad[0]:
-            wt = nv.subm_weight_mirror(w)                              # [ci][t'][co] = w[co][T-1-t'][ci]
+            wt = ctx.wt if ctx.wt is not None else nv.subm_weight_mirror(w)       # [ci][t'][co] = w[co][T-1-t'][ci]
             if not ctx.has_dup:
                 dx = nv.subm_conv_fwd(g, wt, None, nbr, rowperm)[:, :cin].to(in_dtype)
             else:
@@ -372,6 +373,7 @@ def lang_head_sums(pred, target, mask):
 # (LangPretrainer._chunked_forward in training, multi-view losses) does not overwrite tensors an autograd graph saved.
 _SHADOW = WeakIdKeyDictionary()          # parameter -> [bf16 tensor, stamp]; keyed by identity (Tensor.__eq__ is elementwise)
 _SHADOW_T = WeakIdKeyDictionary()        # parameter -> (in, out) bf16 copy (register_transposed)
+_SHADOW_M = WeakIdKeyDictionary()        # conv parameter -> tap-mirrored (cin, taps, cout) bf16 copy (register_mirrored)
 
 
 def _stamp(p):
@@ -412,6 +414,36 @@ def refresh_shadows(src, dst):
         pairs = [(d, _SHADOW_T[p]) for p, d in zip(todo_s, todo_d) if p in _SHADOW_T]
         if pairs:
             nv.transpose16_group(pairs)       # the (in, out) copies the dgrad GEMM reads, refreshed with their shadows
+        pairs = [(d.view(d.shape[0], -1, d.shape[-1]), _SHADOW_M[p]) for p, d in zip(todo_s, todo_d) if p in _SHADOW_M]
+        if pairs:
+            nv.subm_weight_mirror_group(pairs)   # the tap-mirrored (cin, taps, cout) copies the conv dgrad reads
+
+
+def register_mirrored(weights):
+    """SubMConv3d weights (cout, k, k, k, cin): keep the tap-mirrored transpose the dgrad conv reads beside the bf16 shadow, all of them
+    rewritten by one launch when the shadows are re-cast (22 small launches per backward pass otherwise).  Widths that need padding
+    (cin % 8) and the split-precision convs build theirs on the fly as before."""
+    for p in weights:
+        ent = _SHADOW.get(p)
+        if ent is None or p.dim() != 5 or p.shape[-1] % 8:
+            continue
+        cout, cin = p.shape[0], p.shape[-1]
+        taps = p.numel() // (cout * cin)
+        m = _SHADOW_M.get(p)
+        if m is None or m.shape != (cin, taps, cout) or m.device != p.device:
+            _SHADOW_M[p] = torch.empty((cin, taps, cout), dtype=torch.bfloat16, device=p.device)
+            ent[1] = None
+
+
+def mirrored_of(p):
+    """The mirrored bf16 copy of a registered conv weight while its shadow is current, else None."""
+    if not isinstance(p, torch.nn.Parameter):
+        return None
+    m = _SHADOW_M.get(p)
+    if m is None:
+        return None
+    ent = _SHADOW.get(p)
+    return m if (ent is not None and ent[1] == _stamp(p)) else None
 
 
 def register_transposed(weights):

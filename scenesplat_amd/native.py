@@ -463,6 +463,23 @@ def group_partial_sums(items):
     check(lib().ss_group_partial_sums(_p(d_dev), _p(s_dev), len(items), starts[-1], _stream()), "ss_group_partial_sums")
 
 
+def subm_weight_mirror_group(pairs):
+    """ONE launch: wt (cin, taps, cout) = tap-mirrored transpose of w (cout, taps, cin) for every (w, wt) bf16 pair."""
+    import numpy as np
+    if not pairs:
+        return
+    dev = pairs[0][0].device
+    desc = np.zeros((len(pairs), 5), dtype=np.int64)
+    starts = [0]
+    for j, (w, wt) in enumerate(pairs):
+        cout, taps, cin = w.shape
+        _req(w, torch.bfloat16, "w"); _req(wt, torch.bfloat16, "wt", (cin, taps, cout))
+        desc[j] = (w.data_ptr(), wt.data_ptr(), cout, taps, cin)
+        starts.append(starts[-1] + taps * ((cout + 31) // 32) * ((cin + 31) // 32))
+    d_dev, s_dev = _upload_descriptors(desc, starts, dev)
+    check(lib().ss_subm_weight_mirror_group(_p(d_dev), _p(s_dev), len(pairs), starts[-1], _stream()), "ss_subm_weight_mirror_group")
+
+
 def transpose16_group(pairs):
     """ONE launch: dst (cols, rows) = src (rows, cols)^T for every (src, dst) pair of 2-byte tensors (bf16 weight copies)."""
     import numpy as np

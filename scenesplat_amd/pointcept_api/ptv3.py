@@ -402,6 +402,9 @@ class PointTransformerV3(PointModule):
                     wide += [m.weight for m in st.modules() if isinstance(m, nn.Linear) and m.weight.numel() >= 65536]
             if RUNTIME.get("dgrad_nt", True):
                 SF.register_transposed(wide)
+            # dgrad weights of the convs that run on plain bf16 operands: mirrored once per refresh instead of once per backward call
+            SF.register_mirrored([m.weight for m in self.modules() if isinstance(m, SubMConv3d)
+                                  and conv_dtype_for(m.weight.shape[0]) == torch.bfloat16])
             # fp32 accumulators of the weight / bias gradients: one zero-filled arena per step
             total = sum(((p.numel() + 3) & ~3) for p in params if p is not None) + 4 * len(params)
             ps = (src, dst, next(self.parameters()).device, total)

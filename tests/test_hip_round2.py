@@ -535,3 +535,14 @@ def test_transposed_weight_copies_feed_the_linear_dgrad():
     assert torch.equal(SF.bf16_t_of(lin.weight), lin.weight.detach().to(torch.bfloat16).t().contiguous())
     _, dx2, _ = run()
     assert (dx2 - 1.5 * dx0).norm() <= 1e-2 * (1.5 * dx0).norm()
+
+
+def test_grouped_weight_mirror_equals_per_weight_launches():
+    from scenesplat_amd import native as nv
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ws = [torch.randn(co, t, ci, device="cuda", generator=g).to(torch.bfloat16) for co, t, ci in ((768, 27, 768), (32, 125, 16), (48, 27, 40), (8, 1, 8))]
+    outs = [torch.empty(w.shape[2], w.shape[1], w.shape[0], dtype=torch.bfloat16, device="cuda") for w in ws]
+    nv.subm_weight_mirror_group(list(zip(ws, outs)))
+    for w, o in zip(ws, outs):
+        assert torch.equal(o, nv.subm_weight_mirror(w))
+        assert torch.equal(o, w.flip(1).permute(2, 1, 0).contiguous())
