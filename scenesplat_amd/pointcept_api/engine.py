@@ -320,6 +320,7 @@ class Trainer(TrainerBase):
         sched.setdefault("total_steps", max(1, len(train_loader)) * self.max_epoch)
         self.scheduler = build_scheduler(sched, self.optimizer)
         self.scaler = None   # bf16 autocast needs no loss scaling
+        self._steady, self._steady_host = None, {}
         self.comm_info["iter_per_epoch"] = len(train_loader)
         self.register_hooks(cfg.get("hooks", []))
 
@@ -349,12 +350,47 @@ class Trainer(TrainerBase):
             self.after_epoch()
         self.after_train()
 
+    # -- optional steady-state path (cfg["steady_state"] = True; single rank, CUDA) ---------------------------------------
+    # Forward + backward of batches whose integer plan has a shape seen before are replayed as ONE hipGraph launch
+    # (scenesplat_amd/steady_state.py); optimizer, scheduler, gradient clipping and the hooks stay where they are.  Batches of
+    # any other shape, and models whose step reads values on the host, run eagerly through the same object (LangPretrainer with all three
+    # criteria is capturable: the segmented-sum contrastive loss has no host read).  The reference has no counterpart
+    # (pointcept/engines/train.py:142-196 launches every kernel of every step from Python).
+    def _steady_run_step(self, inp, amp):
+        from ..steady_state import SteadyStateStep
+        model = self.model
+        backbone = getattr(model, "backbone", model)
+        if self._steady is None:
+            def fwd_bwd(plan, tensors):
+                d = dict(self._steady_host); d.update(tensors); d["plan"] = plan
+                with torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=amp):
+                    out = model(d)
+                out["loss"].backward()
+                return {k: v for k, v in out.items() if torch.is_tensor(v)}
+            self._steady = SteadyStateStep(fwd_bwd, [p for p in model.parameters() if p.requires_grad], warmup=1)
+        tensors = {k: v for k, v in inp.items() if isinstance(v, torch.Tensor) and v.is_cuda}
+        self._steady_host = {k: v for k, v in inp.items() if k not in tensors}
+        key = tuple(sorted((k, repr(v)) for k, v in self._steady_host.items() if isinstance(v, (int, float, bool, str, type(None)))))
+        plan = backbone.prepare_plan(inp)
+        self.optimizer.zero_grad(set_to_none=True)
+        return self._steady(plan, tensors, key=(key, bool(model.training)))
+
     def run_step(self):
         inp = self.comm_info["input_dict"]
         for k, v in inp.items():
             if isinstance(v, torch.Tensor):
                 inp[k] = v.to(self.device, non_blocking=True)
         amp = bool(self.cfg.get("enable_amp")) and self.device.type == "cuda"
+        if (self.cfg.get("steady_state") and self.device.type == "cuda" and get_world_size() == 1
+                and hasattr(getattr(self.model, "backbone", self.model), "prepare_plan")):
+            inp["epoch_progress"] = self.epoch / self.max_epoch
+            out = self._steady_run_step(inp, amp)
+            if self.cfg.get("clip_grad") is not None:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.cfg["clip_grad"])
+            self.optimizer.step()
+            self.scheduler.step()
+            self.comm_info["model_output_dict"] = out
+            return
         with torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=amp):
             inp["epoch_progress"] = self.epoch / self.max_epoch
             out = self.model(inp)

@@ -6,8 +6,8 @@ scene, the evaluator's chunk_size slices, the synthetic room of bench.py -- the 
 `torch.cuda.graph` (a hipGraph on ROCm) and later steps copy their plan tensors and inputs into the captured addresses
 (ScenePlan.load_from: one multi-tensor copy per dtype) and replay: the host enqueues a plan build, two copies and one
 graph launch instead of a thousand kernels.  Batches with any other shape run eagerly, as does everything when
-capture is refused (a host read inside the step, e.g. the per-class loop of AggregatedContrastiveLoss: found by one eager step under
-torch's sync detector before any capture is attempted).
+capture is refused (a host read inside the step: found by one eager step per signature under torch's sync detector before any
+capture is attempted).
 
 What is inside the graph is exactly what the eager step launches: the bf16 parameter shadows are re-cast from the fp32
 parameters at the top of every replay (functional.refresh_shadows), dropout / DropPath draws advance the Philox offset of
@@ -49,36 +49,39 @@ class SteadyStateStep:
         self.warmup, self.max_graphs, self.enabled = int(warmup), int(max_graphs), bool(enabled)
         self._seen, self._graphs = {}, {}
         self.refused = None            # repr of the exception that ended a capture: eager from then on
-        self._checked = False
+        self._checked = set()          # signatures whose eager step passed the sync check (every new signature is checked: a host-side
+                                       # key may open a branch that reads values on the host)
         self.replays = self.eager_steps = 0
 
     @staticmethod
-    def _signature(plan, inputs):
-        return (plan.signature(),) + tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(inputs.items()))
+    def _signature(plan, inputs, key=None):
+        return (plan.signature(), key) + tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(inputs.items()))
 
     def _eager(self, plan, inputs):
         # outputs are handed out DETACHED: a caller holding on to them must not keep this step's autograd graph alive
         self.eager_steps += 1
         return {k: v.detach() for k, v in self.fn(plan, inputs).items()}
 
-    def __call__(self, plan, inputs):
+    def __call__(self, plan, inputs, key=None):
+        """key: hashable summary of every HOST-side value the step's control flow depends on (a loss schedule gate, a mode
+        flag): a captured graph is replayed only for the key it was captured under."""
         if not self.enabled or self.refused is not None:
             return self._eager(plan, inputs)
-        sig = self._signature(plan, inputs)
+        sig = self._signature(plan, inputs, key)
         cap = self._graphs.get(sig)
         if cap is None:
             if len(self._seen) > 256:                          # batches of ever-changing shape: forget the counts
-                self._seen.clear()
+                self._seen.clear(); self._checked.clear()
             self._seen[sig] = self._seen.get(sig, 0) + 1
             if self._seen[sig] <= self.warmup:
                 return self._eager(plan, inputs)
-            if not self._checked:
+            if sig not in self._checked:
                 # One eager step on a SIDE stream with torch's sync detector armed, BEFORE any capture is attempted: what
                 # would poison a capture -- a host read (.item(), .cpu(), a blocking copy), or an autograd graph of an
                 # earlier step that is still referenced (its AccumulateGrad nodes belong to the default stream, which a
                 # capturing stream must not touch) -- shows up here, where nothing needs unwinding.  (A capture that fails
                 # half way cannot be unwound on this stack: ending an invalidated capture crashes inside the runtime.)
-                self._checked = True
+                self._checked.add(sig)
                 main, side = torch.cuda.current_stream(), torch.cuda.Stream()
                 side.wait_stream(main)
                 torch.cuda.set_sync_debug_mode("error")

@@ -28,7 +28,7 @@ def fn(plan, t):
 params = list(model.parameters())
 steady = SteadyStateStep(fn, params, warmup=1)
 if "nocheck" in flags:
-    steady._checked = True
+    steady._checked = {None}   # (obsolete switch of the first experiments)
 g = torch.Generator(device="cuda").manual_seed(1)
 perms0 = model.draw_perms()
 for it in range(5):

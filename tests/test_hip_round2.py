@@ -546,3 +546,51 @@ def test_grouped_weight_mirror_equals_per_weight_launches():
     for w, o in zip(ws, outs):
         assert torch.equal(o, nv.subm_weight_mirror(w))
         assert torch.equal(o, w.flip(1).permute(2, 1, 0).contiguous())
+
+
+def test_trainer_steady_state_option_replays_and_matches_the_eager_trainer():
+    """cfg["steady_state"] = True: the Trainer replays forward + backward of repeated batch shapes as a hipGraph and ends, after the
+    same batches, with the weights of the plain Trainer (bf16 noise apart); the aggregated contrastive loss (random half split, class sums by
+    sort + segment sums, no host reads) is captured with the rest."""
+    import tempfile
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.pointcept_api import engine
+    from scenesplat_amd.synthetic import room_chunk
+
+    def loader(k=6):
+        base = room_chunk(n_side=40, seed=3, lang_dim=48, num_classes=4)
+        g = torch.Generator().manual_seed(0)
+        out = []
+        for _ in range(k):
+            d = {kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in base.items()}
+            d["feat"] = torch.randn(d["feat"].shape, generator=g)
+            d["lang_feat"] = F.normalize(torch.randn(d["lang_feat"].shape, generator=g), dim=1)
+            out.append(d)
+        return out
+
+    def cfg(tmp, crit, steady):
+        return dict(model=dict(type="LangPretrainer", backbone=dict(type="PT-v3m1", **TINY, drop_path=0.0, shuffle_orders=False), criteria=crit),
+                    device="cuda", eval_epoch=1, save_path=tmp, enable_amp=True, clip_grad=1.0, steady_state=steady,
+                    optimizer=dict(type="AdamW", lr=2e-3, weight_decay=0.05),
+                    scheduler=dict(type="OneCycleLR", max_lr=2e-3, pct_start=0.3, anneal_strategy="cos", div_factor=10.0, final_div_factor=100.0),
+                    hooks=[])
+    with _Runtime(conv_dtype=torch.bfloat16, attn_impl=nv.ATTN_MFMA), tempfile.TemporaryDirectory() as tmp:
+        weights = {}
+        for steady in (False, True):
+            torch.manual_seed(21)
+            tr = engine.Trainer(cfg(tmp, CRIT[:2], steady), train_loader=loader())
+            tr.train()
+            weights[steady] = torch.cat([p.detach().float().flatten() for p in tr.model.parameters()])
+            if steady:
+                assert tr._steady is not None and tr._steady.refused is None, tr._steady.refused
+                assert tr._steady.replays == 4 and tr._steady.eager_steps == 2          # warm-up, checked step, then the graph
+        rel = float((weights[True] - weights[False]).norm() / weights[False].norm())
+        assert rel < 2e-2, rel
+        # contrastive loss with its gate open (epoch_progress is 0 in the only epoch: a schedule that is always on)
+        crit = CRIT[:2] + [dict(type="AggregatedContrastiveLoss", temperature=0.2, reduction="mean", loss_weight=0.02, schedule="all")]
+        torch.manual_seed(21)
+        tr = engine.Trainer(cfg(tmp, crit, True), train_loader=loader(4))
+        tr.train()
+        # (the segmented-sum form of the contrastive loss reads nothing on the host either: the whole criteria stack is replayed)
+        assert tr._steady.refused is None and tr._steady.replays == 2, (tr._steady.refused, tr._steady.replays)
+        assert all(torch.isfinite(p).all() for p in tr.model.parameters())
