@@ -579,7 +579,10 @@ def defer_marker(x):
 # construction: the stage's parameters enter the stage through an identity node (_StageParams) whose backward runs after
 # every consumer inside the stage has returned -- it launches the group and only then hands the (already returned,
 # zero-initialised, stream-ordered) gradient buffers on to AccumulateGrad and the bucket hooks.
-WGRAD_GROUP_MAX_ROWS = int(os.environ.get("SS_WGRAD_GROUP_MAX", "32768"))    # 0 disables grouping
+# every stage is grouped: with the CUs shared out over the tiles of the whole group (ss_linear_wgrad_group_plan2) the full-resolution stage gains
+# too (room-102400 40.4 -> 40.0 ms/step, uniform-102400 68.0 -> 65.6 against the round-2 cap of 32,768 rows); the queued dy tensors of a stage
+# stay alive until its end (3 GB at dec0 for one chunk)
+WGRAD_GROUP_MAX_ROWS = int(os.environ.get("SS_WGRAD_GROUP_MAX", str(1 << 22)))    # 0 disables grouping
 _STAGE = {"cur": None, "route": {}}
 
 
