@@ -28,6 +28,8 @@ def needs_build():
 
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
+    if os.environ.get("SS_EXTRA_HIPCC_FLAGS"):
+        force = True      # a variant build: the up-to-date check only looks at file times (an unchanged tree would silently keep the old code)
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
