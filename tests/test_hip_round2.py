@@ -287,6 +287,57 @@ def test_ddp_two_ranks_on_the_hip_model_end_with_identical_weights():
     assert all(np.isfinite(v).all() for v in res[0][1].values())
 
 
+def _rccl_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch.distributed as dist
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.pointcept_api import MODELS, RUNTIME
+    from scenesplat_amd.synthetic import room_chunk
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    RUNTIME.update(conv_dtype=torch.bfloat16, attn_impl=nv.ATTN_MFMA)
+    out = {}
+    for wrapped in (False, True):
+        torch.manual_seed(0)
+        model = MODELS.build(dict(type="LangPretrainer", backbone=dict(type="PT-v3m1", **TINY, drop_path=0.0, shuffle_orders=False),
+                                  criteria=CRIT[:2])).cuda().train()
+        # exactly bench.py's wrapper (engines/defaults.py:13-34 with the bucket view / bucket size of the bench)
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True,
+                                                        bucket_cap_mb=100) if wrapped else model
+        opt = torch.optim.SGD(net.parameters(), lr=1e-2)
+        for step in range(2):
+            d = {k: v.cuda() for k, v in room_chunk(n_side=32, seed=step, lang_dim=48, num_classes=4).items()}
+            d["epoch_progress"] = 0.1
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = net(d)["loss"]
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        out[wrapped] = torch.cat([p.detach().float().flatten() for p in model.parameters()]).cpu().numpy()
+    q.put((out[False], out[True], dist.get_backend()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ddp_over_rccl_single_rank_matches_the_unwrapped_model():
+    """The N > 1 path of bench.py on RCCL itself, as far as one GPU allows: a one-rank "nccl" process group, the HIP LangPretrainer
+    under DistributedDataParallel with bench.py's arguments (bucket views, 100 MB buckets), two optimizer steps -- RCCL's communicator,
+    the bucket hooks on the custom autograd Functions and the fp32 gradient arena all run; the weights equal those of the unwrapped
+    model (a one-rank all-reduce is the identity; bf16 noise apart)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    plain, ddp, backend = q.get(timeout=500)
+    p.join(60)
+    assert p.exitcode == 0 and backend == "nccl"
+    assert np.isfinite(ddp).all()
+    assert np.linalg.norm(ddp - plain) <= 2e-2 * np.linalg.norm(plain)
+
+
 # ---- GPU data fast path: SphereCrop / Collect / collate (SURVEY 8f rank 3) -----------------------------------------
 def test_gpu_sphere_crop_collect_collate_against_reference_semantics():
     """pointcept/datasets/transform.py:1420-1548 (SphereCrop random / center), :320-352 (Collect) and
