@@ -271,6 +271,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # SS_BENCH_FORCE_DDP=1 (DIAGNOSTIC, single rank): a one-rank RCCL process group and the DDP wrapper of the N > 1 path -- bucket hooks,
+    # bucket views and a (trivial) all-reduce per bucket run as they do with more ranks; the line it prints is not the metric
+    force_ddp = world == 1 and os.environ.get("SS_BENCH_FORCE_DDP") == "1"
+    if force_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
@@ -292,7 +298,7 @@ def main():
     torch.manual_seed(1234 + rank)
     model = MODELS.build(dict(type="PT-v3m1", **LANG_PTV3)).to(dev).train()
     net = model
-    if world > 1:
+    if world > 1 or force_ddp:
         # DDP as the reference builds it (engines/defaults.py:13-34): broadcast_buffers=False
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
                                                         gradient_as_bucket_view=True, bucket_cap_mb=100)
@@ -323,7 +329,7 @@ def main():
     # steps the ~1,100 launches of forward + backward are captured in a hipGraph and later steps replay it -- the plan is
     # still built anew every step (on the side stream) and copied into the captured plan's tensors; every kernel still
     # runs.  With more than one rank the step stays eager: DDP's bucket hooks are host callbacks.
-    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    use_graph = (args.graph == "on" or (args.graph == "auto" and world == 1)) and not force_ddp
     from scenesplat_amd.steady_state import SteadyStateStep
     steady = SteadyStateStep(fwd_bwd, list(model.parameters()), warmup=1, enabled=use_graph)
 
@@ -391,7 +397,8 @@ def main():
             "metric": "Gaussians/s encoder fwd+bwd, 102k-pt chunks", "value": world * n * args.steps / dt,
             "unit": "Gaussians/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic" if os.environ.get("SS_BENCH_REUSE_PLAN") != "1" else "synthetic, DIAGNOSTIC: plan reused (invalid as metric)",
+            "dtype": "bf16", "data": ("synthetic, DIAGNOSTIC: one-rank DDP rehearsal (invalid as metric)" if force_ddp else
+                                     "synthetic" if os.environ.get("SS_BENCH_REUSE_PLAN") != "1" else "synthetic, DIAGNOSTIC: plan reused (invalid as metric)"),
             "config": {"workload": (("uniform-%d (stress fixture, NOT the metric workload):" if args.fixture == "uniform" else "room-%d:")
                                     + " PT-v3m1 lang-pretrain encoder (91.71M params, in=11, out=768) fwd+bwd, "
                                     "1 chunk of %d Gaussians per GPU per step, serialization included") % (n, n),
@@ -426,7 +433,7 @@ def main():
             if not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(args.cpu_n_side, log)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or force_ddp:
         dist.destroy_process_group()
 
 
