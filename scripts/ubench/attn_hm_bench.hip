@@ -1,0 +1,260 @@
+// Stand-alone harness of the head-major (round 3) attention kernels: correctness against a naive fp32 kernel on the same bf16
+// operands, then timing at the dec0 shape (100 windows x 16 heads, K = 1024, d = 48).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I scenesplat_amd/csrc [-DHM_ABL=m] \
+//         scripts/ubench/attn_hm_bench.hip -o scripts/ubench/bin/attn_hm_bench
+// HM_ABL bits (forward): 1 no DMA, 2 no barrier, 4 exp -> mul, 8 no max / rescale, 16 no PV MFMAs, 32 no QK^T MFMAs, 64 no stores
+#include "../../scenesplat_amd/csrc/attention_hm.hip"
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include <numeric>
+#include <random>
+
+static float bf2f(unsigned short v) { unsigned int u = (unsigned int)v << 16; float f; memcpy(&f, &u, 4); return f; }
+
+// naive reference: one thread per (window, head, query); fp32
+__global__ void k_ref_fwd(const unsigned short* hm, int64_t NP, const int32_t* win_start, int H, int D, float scale,
+                          const int* wlist, int nw, float* oref, float* lref, int K) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int q = idx % K; int h = (idx / K) % H; int wi = idx / (K * H);
+  if (wi >= nw) return;
+  int w = wlist[wi]; int p0 = win_start[w], L = win_start[w + 1] - p0;
+  if (q >= L) return;
+  const int64_t sec = (int64_t)H * NP * D;
+  const unsigned short* qp = hm + ((int64_t)h * NP + p0 + q) * D;
+  float mx = -1e30f;
+  for (int k = 0; k < L; ++k) {
+    const unsigned short* kp = hm + sec + ((int64_t)h * NP + p0 + k) * D;
+    float s = 0; for (int d = 0; d < D; ++d) s += bf16_to_f32(qp[d]) * bf16_to_f32(kp[d]);
+    mx = fmaxf(mx, s * scale);   // scale = ln 2: the q section holds q * softmax_scale * log2(e)
+  }
+  float l = 0; float acc[64]; for (int d = 0; d < D; ++d) acc[d] = 0;
+  for (int k = 0; k < L; ++k) {
+    const unsigned short* kp = hm + sec + ((int64_t)h * NP + p0 + k) * D;
+    const unsigned short* vp = hm + 2 * sec + ((int64_t)h * NP + p0 + k) * D;
+    float s = 0; for (int d = 0; d < D; ++d) s += bf16_to_f32(qp[d]) * bf16_to_f32(kp[d]);
+    float p = __expf(s * scale - mx); l += p;
+    for (int d = 0; d < D; ++d) acc[d] += p * bf16_to_f32(vp[d]);
+  }
+  float* op = oref + ((int64_t)(wi * H + h) * K + q) * D;
+  for (int d = 0; d < D; ++d) op[d] = acc[d] / l;
+  lref[(int64_t)(wi * H + h) * K + q] = mx + logf(l);
+}
+
+// naive backward references (fp32 on the same bf16 operands).  Pass 1, one thread per (window, head, query): lse2, delta, dq.
+__global__ void k_ref_bwd_q(const unsigned short* hm, int64_t NP, const unsigned short* dout, const unsigned short* outp,
+                            const int32_t* sidx, const int32_t* win_start, int H, int D, float sm_scale, const int* wlist, int nw,
+                            float* lse2, float* delta, float* dqref, int K) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int q = idx % K; int h = (idx / K) % H; int wi = idx / (K * H);
+  if (wi >= nw) return;
+  int w = wlist[wi]; int p0 = win_start[w], L = win_start[w + 1] - p0;
+  if (q >= L) return;
+  const int C = H * D;
+  const int64_t sec = (int64_t)H * NP * D;
+  const unsigned short* qp = hm + ((int64_t)h * NP + p0 + q) * D;
+  int sr = sidx[p0 + q];
+  float go[64], oo[64];
+  for (int d = 0; d < D; ++d) { go[d] = sr >= 0 ? bf16_to_f32(dout[(int64_t)sr * C + h * D + d]) : 0.f; oo[d] = sr >= 0 ? bf16_to_f32(outp[(int64_t)sr * C + h * D + d]) : 0.f; }
+  float mx = -1e30f;
+  for (int k = 0; k < L; ++k) {
+    const unsigned short* kp = hm + sec + ((int64_t)h * NP + p0 + k) * D;
+    float s = 0; for (int d = 0; d < D; ++d) s += bf16_to_f32(qp[d]) * bf16_to_f32(kp[d]);
+    mx = fmaxf(mx, s);
+  }
+  float l = 0;
+  for (int k = 0; k < L; ++k) {
+    const unsigned short* kp = hm + sec + ((int64_t)h * NP + p0 + k) * D;
+    float s = 0; for (int d = 0; d < D; ++d) s += bf16_to_f32(qp[d]) * bf16_to_f32(kp[d]);
+    l += exp2f(s - mx);
+  }
+  float l2 = mx + log2f(l), dl = 0;
+  for (int d = 0; d < D; ++d) dl += go[d] * oo[d];
+  float acc[64]; for (int d = 0; d < D; ++d) acc[d] = 0;
+  for (int k = 0; k < L; ++k) {
+    const unsigned short* kp = hm + sec + ((int64_t)h * NP + p0 + k) * D;
+    const unsigned short* vp = hm + 2 * sec + ((int64_t)h * NP + p0 + k) * D;
+    float s = 0, dp = 0;
+    for (int d = 0; d < D; ++d) { s += bf16_to_f32(qp[d]) * bf16_to_f32(kp[d]); dp += go[d] * bf16_to_f32(vp[d]); }
+    float ds = exp2f(s - l2) * (dp - dl);
+    for (int d = 0; d < D; ++d) acc[d] += ds * bf16_to_f32(kp[d]);
+  }
+  int64_t o = (int64_t)(wi * H + h) * K + q;
+  lse2[o] = l2; delta[o] = dl;
+  for (int d = 0; d < D; ++d) dqref[o * D + d] = acc[d] * sm_scale;
+}
+// pass 2, one thread per (window, head, key): dk, dv
+__global__ void k_ref_bwd_k(const unsigned short* hm, int64_t NP, const unsigned short* dout, const int32_t* sidx,
+                            const int32_t* win_start, int H, int D, const int* wlist, int nw, const float* lse2,
+                            const float* delta, float* dkref, float* dvref, int K) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int k = idx % K; int h = (idx / K) % H; int wi = idx / (K * H);
+  if (wi >= nw) return;
+  int w = wlist[wi]; int p0 = win_start[w], L = win_start[w + 1] - p0;
+  if (k >= L) return;
+  const int C = H * D;
+  const int64_t sec = (int64_t)H * NP * D;
+  const unsigned short* kp = hm + sec + ((int64_t)h * NP + p0 + k) * D;
+  const unsigned short* vp = hm + 2 * sec + ((int64_t)h * NP + p0 + k) * D;
+  float ak[64], av[64]; for (int d = 0; d < D; ++d) { ak[d] = 0; av[d] = 0; }
+  for (int q = 0; q < L; ++q) {
+    const unsigned short* qp = hm + ((int64_t)h * NP + p0 + q) * D;
+    int sr = sidx[p0 + q];
+    float s = 0, dp = 0;
+    for (int d = 0; d < D; ++d) {
+      float g = sr >= 0 ? bf16_to_f32(dout[(int64_t)sr * C + h * D + d]) : 0.f;
+      s += bf16_to_f32(qp[d]) * bf16_to_f32(kp[d]); dp += g * bf16_to_f32(vp[d]);
+    }
+    int64_t o = (int64_t)(wi * H + h) * K + q;
+    float p = exp2f(s - lse2[o]), ds = p * (dp - delta[o]);
+    for (int d = 0; d < D; ++d) {
+      float g = sr >= 0 ? bf16_to_f32(dout[(int64_t)sr * C + h * D + d]) : 0.f;
+      ak[d] += ds * bf16_to_f32(qp[d]); av[d] += p * g;
+    }
+  }
+  int64_t o = (int64_t)(wi * H + h) * K + k;
+  for (int d = 0; d < D; ++d) { dkref[o * D + d] = ak[d] * 0.69314718056f; dvref[o * D + d] = av[d]; }
+}
+
+int main(int argc, char** argv) {
+  const int D = argc > 1 ? atoi(argv[1]) : 48;
+  const int W = argc > 2 ? atoi(argv[2]) : 100, K = argc > 3 ? atoi(argv[3]) : 1024, H = 16, C = H * D;
+  const int Ltail = argc > 4 ? atoi(argv[4]) : K;         // length of the LAST window (a short tail window)
+  const int NB = argc > 5 ? atoi(argv[5]) : 8;             // borrowed (duplicate-padding) slots at the end of the last window
+  const int64_t NP = (int64_t)(W - 1) * K + Ltail, n = NP - NB;
+  std::vector<unsigned short> hm((size_t)3 * H * NP * D);
+  std::mt19937 rng(1);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  const float c2 = 1.44269504f / sqrtf((float)D);
+  for (size_t i = 0; i < hm.size(); ++i) {
+    float f = nd(rng); if (i < (size_t)H * NP * D) f *= c2;      // section 0 = q * softmax_scale * log2(e)
+    unsigned int u; memcpy(&u, &f, 4); hm[i] = (unsigned short)((u + 0x7fff + ((u >> 16) & 1)) >> 16);
+  }
+  // a few large scores so that the lazy rescale branch fires late in a window
+  for (int d = 0; d < D; ++d) { hm[(size_t)(0 * NP + 5) * D + d] = 0x4000; hm[(size_t)H * NP * D + (size_t)(0 * NP + 900 % K) * D + d] = 0x4080; }
+  std::vector<int32_t> sidx(NP), win(W + 1);
+  std::iota(sidx.begin(), sidx.begin() + n, 0);
+  std::shuffle(sidx.begin(), sidx.begin() + n, rng);
+  for (int64_t p = n; p < NP; ++p) sidx[p] = -1 - (int32_t)(p - n);
+  for (int w = 0; w < W; ++w) win[w] = w * K;
+  win[W] = (int32_t)NP;
+  unsigned short *dhm, *dout; int32_t *ds, *dw; float* dlse;
+  hipMalloc(&dhm, hm.size() * 2); hipMalloc(&dout, (size_t)n * C * 2); hipMalloc(&ds, NP * 4); hipMalloc(&dw, (W + 1) * 4);
+  hipMalloc(&dlse, (size_t)H * NP * 4);
+  hipMemcpy(dhm, hm.data(), hm.size() * 2, hipMemcpyHostToDevice);
+  hipMemcpy(ds, sidx.data(), NP * 4, hipMemcpyHostToDevice);
+  hipMemcpy(dw, win.data(), (W + 1) * 4, hipMemcpyHostToDevice);
+  hipMemset(dout, 0, (size_t)n * C * 2);
+  const float scale = 0.69314718056f;
+  int rc = ss_attn_hm_fwd(dhm, NP, ds, dw, W, K, dout, dlse, C, H, scale, 0);
+  if (rc || hipDeviceSynchronize() != hipSuccess) { printf("launch failed rc=%d %s\n", rc, hipGetErrorString(hipGetLastError())); return 1; }
+#if HM_ABL == 0
+  {
+    std::vector<int> wl = {0, W / 2, W - 1};
+    int nw = (int)wl.size(); int* dwl; float *doref, *dlref;
+    hipMalloc(&dwl, nw * 4); hipMemcpy(dwl, wl.data(), nw * 4, hipMemcpyHostToDevice);
+    hipMalloc(&doref, (size_t)nw * H * K * D * 4); hipMalloc(&dlref, (size_t)nw * H * K * 4);
+    hipMemset(doref, 0, (size_t)nw * H * K * D * 4);
+    int tot = nw * H * K;
+    hipLaunchKernelGGL(k_ref_fwd, dim3((tot + 255) / 256), dim3(256), 0, 0, dhm, NP, dw, H, D, scale, dwl, nw, doref, dlref, K);
+    std::vector<float> oref((size_t)nw * H * K * D), lref((size_t)nw * H * K);
+    std::vector<unsigned short> out((size_t)n * C); std::vector<float> lse((size_t)H * NP);
+    hipMemcpy(oref.data(), doref, oref.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(lref.data(), dlref, lref.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(out.data(), dout, out.size() * 2, hipMemcpyDeviceToHost);
+    hipMemcpy(lse.data(), dlse, lse.size() * 4, hipMemcpyDeviceToHost);
+    double maxerr = 0, maxl = 0; double num = 0, den = 0;
+    for (int wi = 0; wi < nw; ++wi) {
+      int w = wl[wi]; int p0 = win[w], L = win[w + 1] - p0;
+      for (int h = 0; h < H; ++h) for (int q = 0; q < L; ++q) {
+        int64_t row = sidx[p0 + q];
+        if (row >= 0) for (int d = 0; d < D; ++d) {
+          double r = oref[((size_t)(wi * H + h) * K + q) * D + d], g = bf2f(out[(size_t)row * C + h * D + d]);
+          maxerr = std::max(maxerr, fabs(r - g)); num += (r - g) * (r - g); den += r * r;
+        }
+        double l2 = -lse[(size_t)h * NP + p0 + q];
+        double lr_ = lref[(size_t)(wi * H + h) * K + q] * 1.4426950408889634;
+        maxl = std::max(maxl, fabs(l2 - lr_));
+      }
+    }
+    printf("fwd check d=%d W=%d K=%d Ltail=%d: max |dO| %.3e  rel L2 %.3e  max |dlse2| %.3e  -> %s\n", D, W, K, Ltail, maxerr, sqrt(num / den), maxl,
+           (sqrt(num / den) < 6e-3 && maxl < 2e-2) ? "OK" : "MISMATCH");
+  }
+#endif
+  // ---------------- backward ----------------
+  std::vector<unsigned short> gout((size_t)n * C);
+  for (auto& v : gout) { float f = nd(rng); unsigned int u; memcpy(&u, &f, 4); v = (unsigned short)((u + 0x7fff + ((u >> 16) & 1)) >> 16); }
+  unsigned short *dgo, *ddoh, *ddqkv, *dextra; float* dndel;
+  hipMalloc(&dgo, gout.size() * 2); hipMalloc(&ddoh, (size_t)H * NP * D * 2); hipMalloc(&ddqkv, (size_t)n * 3 * C * 2);
+  hipMalloc(&dextra, (size_t)(NB + 1) * 2 * C * 2); hipMalloc(&dndel, (size_t)H * NP * 4);
+  hipMemcpy(dgo, gout.data(), gout.size() * 2, hipMemcpyHostToDevice);
+  hipMemset(ddqkv, 0, (size_t)n * 3 * C * 2); hipMemset(dextra, 0, (size_t)(NB + 1) * 2 * C * 2);
+  const float sm_scale = 1.f / sqrtf((float)D);
+  auto bwd = [&]() {
+    int r1 = ss_attn_hm_dq(dhm, NP, dgo, dout, dlse, dndel, ddoh, ds, dw, W, K, ddqkv, C, H, sm_scale, 0);
+    int r2 = ss_attn_hm_dkv(dhm, NP, ddoh, dlse, dndel, ds, dw, W, K, ddqkv, dextra, C, H, 0);
+    return r1 | r2;
+  };
+  rc = bwd();
+  if (rc || hipDeviceSynchronize() != hipSuccess) { printf("bwd launch failed rc=%d %s\n", rc, hipGetErrorString(hipGetLastError())); return 1; }
+#if HM_ABL == 0
+  {
+    std::vector<int> wl = {0, W / 2, W - 1};
+    int nw = (int)wl.size(); int* dwl; float *dl2, *ddl, *dqr, *dkr, *dvr;
+    size_t tot = (size_t)nw * H * K;
+    hipMalloc(&dwl, nw * 4); hipMemcpy(dwl, wl.data(), nw * 4, hipMemcpyHostToDevice);
+    hipMalloc(&dl2, tot * 4); hipMalloc(&ddl, tot * 4); hipMalloc(&dqr, tot * D * 4); hipMalloc(&dkr, tot * D * 4); hipMalloc(&dvr, tot * D * 4);
+    hipLaunchKernelGGL(k_ref_bwd_q, dim3((tot + 255) / 256), dim3(256), 0, 0, dhm, NP, dgo, dout, ds, dw, H, D, sm_scale, dwl, nw, dl2, ddl, dqr, K);
+    hipLaunchKernelGGL(k_ref_bwd_k, dim3((tot + 255) / 256), dim3(256), 0, 0, dhm, NP, dgo, ds, dw, H, D, dwl, nw, dl2, ddl, dkr, dvr, K);
+    std::vector<float> qr(tot * D), kr(tot * D), vr(tot * D);
+    std::vector<unsigned short> g((size_t)n * 3 * C), ex((size_t)(NB + 1) * 2 * C);
+    hipMemcpy(qr.data(), dqr, qr.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(kr.data(), dkr, kr.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(vr.data(), dvr, vr.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(g.data(), ddqkv, g.size() * 2, hipMemcpyDeviceToHost); hipMemcpy(ex.data(), dextra, ex.size() * 2, hipMemcpyDeviceToHost);
+    double num[3] = {0, 0, 0}, den[3] = {0, 0, 0}, mxe[3] = {0, 0, 0};
+    for (int wi = 0; wi < nw; ++wi) {
+      int w = wl[wi]; int p0 = win[w], L = win[w + 1] - p0;
+      for (int h = 0; h < H; ++h) for (int q = 0; q < L; ++q) {
+        int64_t row = sidx[p0 + q]; size_t o = ((size_t)(wi * H + h) * K + q) * D;
+        for (int d = 0; d < D; ++d) {
+          double r[3] = {qr[o + d], kr[o + d], vr[o + d]}, v[3];
+          if (row >= 0) { for (int s3 = 0; s3 < 3; ++s3) v[s3] = bf2f(g[(size_t)row * 3 * C + s3 * C + h * D + d]); }
+          else { v[0] = r[0]; for (int s3 = 1; s3 < 3; ++s3) v[s3] = bf2f(ex[(size_t)(-1 - row) * 2 * C + (s3 - 1) * C + h * D + d]); }
+          for (int s3 = 0; s3 < 3; ++s3) { num[s3] += (r[s3] - v[s3]) * (r[s3] - v[s3]); den[s3] += r[s3] * r[s3]; mxe[s3] = std::max(mxe[s3], fabs(r[s3] - v[s3])); }
+        }
+      }
+    }
+    bool ok = true; for (int s3 = 0; s3 < 3; ++s3) ok = ok && sqrt(num[s3] / den[s3]) < 8e-3;
+    printf("bwd check d=%d: rel L2 dq %.3e dk %.3e dv %.3e  (max abs %.2e %.2e %.2e) -> %s\n", D, sqrt(num[0] / den[0]), sqrt(num[1] / den[1]),
+           sqrt(num[2] / den[2]), mxe[0], mxe[1], mxe[2], ok ? "OK" : "MISMATCH");
+  }
+#endif
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  {
+    for (int i = 0; i < 3; ++i) bwd();
+    hipDeviceSynchronize();
+    float msq, msk;
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 20; ++i) ss_attn_hm_dq(dhm, NP, dgo, dout, dlse, dndel, ddoh, ds, dw, W, K, ddqkv, C, H, sm_scale, 0);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&msq, e0, e1); msq /= 20;
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < 20; ++i) ss_attn_hm_dkv(dhm, NP, ddoh, dlse, dndel, ds, dw, W, K, ddqkv, dextra, C, H, 0);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1); hipEventElapsedTime(&msk, e0, e1); msk /= 20;
+    const double flb = (double)W * H * 10.0 * K * K * D;
+    printf("attn hm bwd d=%d: dq %.3f ms + dkv %.3f ms = %.3f ms  %.0f TFLOP/s (%.1f %% of 2.5 PF)\n", D, msq, msk, msq + msk,
+           flb / (msq + msk) / 1e9, flb / (msq + msk) / 1e9 / 25.0);
+  }
+  for (int i = 0; i < 3; ++i) ss_attn_hm_fwd(dhm, NP, ds, dw, W, K, dout, dlse, C, H, scale, 0);
+  hipDeviceSynchronize();
+  const int iters = 30;
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < iters; ++i) ss_attn_hm_fwd(dhm, NP, ds, dw, W, K, dout, dlse, C, H, scale, 0);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
+  const double fl = (double)W * H * 4.0 * K * K * D;
+  printf("attn hm fwd d=%d ABL=%d: %.3f ms  %.0f TFLOP/s (%.1f %% of 2.5 PF)\n", D, (int)HM_ABL, ms, fl / ms / 1e9, fl / ms / 1e9 / 25.0);
+  return 0;
+}
