@@ -14,6 +14,8 @@
  *   ss_segment_reduce / ss_segment_bcast      torch_scatter.segment_csr (ptv3:416-421)
  *   ss_gather_rows / ss_scatter_rows / ss_gather_add_rows   feat[idx] row indexing (ptv3:188,216,417,478)
  *   ss_window_attn_fwd / ss_window_attn_bwd   flash_attn.flash_attn_varlen_qkvpacked_func (ptv3:208-214)
+ *   ss_linear_fwd_headmajor + ss_window_attn_hm_fwd / _bwd   the same call together with the qkv projection's output
+ *                                             layout and the qkv[order] gather in front of it (ptv3:172-188, 208-216)
  *   ss_lang_head_fwd / ss_lang_head_bwd       models/default.py:98-109 (F.normalize), losses/misc.py:254-270
  *                                             (CosineSimilarity), :274-295 (L2Loss)
  *   ss_knn_query ... ss_bfs_cluster           libs/pointops/src/pointops_api.cpp:15-31,
@@ -79,6 +81,25 @@ int ss_window_attn_bwd(const void* qkv, const void* out, const void* dout, const
                        const int32_t* sidx, const int32_t* win_start, int num_windows, int max_window, int64_t n,
                        int64_t n_pad, int channels, int num_heads, float scale, int dtype, int impl, void* dqkv,
                        void* workspace, size_t workspace_bytes, ss_stream_t stream);
+
+/* ---- head-major window attention (round 3) ------------------------------------------------------------
+ * hm (sections = 3, num_heads, n_pad, head_dim) bf16: q / k / v of padded slot p of the curve order (slot p = point gidx[p]);
+ * section 0 holds q * softmax_scale * log2(e).  Written by ss_linear_fwd_headmajor (the projection itself, LDS-DMA pipeline
+ * GEMM; needs k % 64 == 0) or by ss_headmajor_pack from an existing (n, sections * channels) projection (fp32 or bf16).
+ * out (n, channels) bf16 in memory row order (rows through sidx); neg_lse2 (num_heads, n_pad) fp32 = -log2 sum exp2(scores).
+ * Backward: dqkv (n, 3 * channels) bf16 in memory row order, gradients w.r.t. the UNSCALED q, k, v. */
+int ss_linear_fwd_headmajor(const void* x, const int32_t* row_index, const void* weight, const float* bias, void* out_hm,
+                            int64_t m, int k, int n_out, int channels, int head_dim, float sec0_scale, ss_stream_t stream);
+int ss_headmajor_pack(const void* src, int in_dtype, const int32_t* gidx, void* hm, int64_t n_pad, int channels,
+                      int num_heads, int sections, float sec0_scale, ss_stream_t stream);
+int ss_window_attn_hm_fwd(const void* hm, const int32_t* sidx, const int32_t* win_start, int num_windows, int max_window,
+                          int64_t n, int64_t n_pad, int channels, int num_heads, void* out, float* neg_lse2,
+                          ss_stream_t stream);
+size_t ss_window_attn_hm_bwd_workspace_bytes(int64_t n, int64_t n_pad, int channels, int num_heads);
+int ss_window_attn_hm_bwd(const void* hm, const void* out, const void* dout, const float* neg_lse2, const int32_t* gidx,
+                          const int32_t* sidx, const int32_t* win_start, int num_windows, int max_window, int64_t n,
+                          int64_t n_pad, int channels, int num_heads, float scale, void* dqkv, void* workspace,
+                          size_t workspace_bytes, ss_stream_t stream);
 
 /* ---- submanifold convolution ------------------------------------------------------------ */
 /* nbr (k^3, n) int32 (tap-major), -1 = no site; zkeys_sorted/zorder: z (or z-trans, swap_xy=1) codes sorted */

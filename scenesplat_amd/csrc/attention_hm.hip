@@ -807,3 +807,81 @@ int ss_attn_hm_dkv(const void* hm, int64_t np, const void* doh, const float* nls
 #undef SS_HK_CASE
   return SS_OK;
 }
+
+// =====================================================================================
+// head-major packing of an existing (n, sections * C) projection (fallback for levels whose projection is not eligible
+// for the fused epilogue of gemm8.hip: k < 64 or not a multiple of 64).  in_dtype SS_F32: the library GEMM's fp32 result, so
+// q is scaled and rounded ONCE, exactly as in the fused epilogue.  One thread per 16-byte output chunk, output order.
+// =====================================================================================
+template <typename InT>
+__global__ void k_hm_pack(const InT* __restrict__ src, const int32_t* __restrict__ gidx, unsigned short* __restrict__ hm,
+                          int64_t NP, int C, int H, int D, int nsec, float sec0_scale) {
+  const int CH = D / 8;
+  const int64_t total = (int64_t)nsec * H * NP * CH;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(e % CH); int64_t r = e / CH;
+    const int64_t p = r % NP; r /= NP;
+    const int h = (int)(r % H); const int sec = (int)(r / H);
+    const InT* sp = src + (int64_t)gidx[p] * nsec * C + (int64_t)sec * C + h * D + ch * 8;
+    const float sc = sec == 0 ? sec0_scale : 1.f;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = ElemIO<InT>::load(sp + i) * sc;
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(hm + e * 8) = o;
+  }
+}
+
+extern "C" int ss_headmajor_pack(const void* src, int in_dtype, const int32_t* gidx, void* hm, int64_t n_pad, int channels,
+                                 int num_heads, int sections, float sec0_scale, hipStream_t stream) {
+  if (channels <= 0 || num_heads <= 0 || channels % num_heads || ((channels / num_heads) & 7) || sections <= 0) return SS_ERR_ARG;
+  if (n_pad == 0) return SS_OK;
+  const int D = channels / num_heads;
+  const int64_t total = (int64_t)sections * n_pad * channels / 8;
+  dim3 g((unsigned)std::min<int64_t>((total + 255) / 256, 65536)), b(256);
+  if (in_dtype == SS_F32)
+    SS_LAUNCH((k_hm_pack<float>), g, b, 0, stream, (const float*)src, gidx, (unsigned short*)hm, n_pad, channels, num_heads, D, sections, sec0_scale);
+  else if (in_dtype == SS_BF16)
+    SS_LAUNCH((k_hm_pack<unsigned short>), g, b, 0, stream, (const unsigned short*)src, gidx, (unsigned short*)hm, n_pad, channels, num_heads, D, sections, sec0_scale);
+  else
+    return SS_ERR_ARG;
+  return SS_OK;
+}
+
+// =====================================================================================
+// C-ABI of the head-major window attention (include/scenesplat_hip.h)
+// =====================================================================================
+static inline size_t hm_al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" int ss_window_attn_hm_fwd(const void* hm, const int32_t* sidx, const int32_t* win_start, int num_windows,
+                                     int max_window, int64_t n, int64_t n_pad, int channels, int num_heads, void* out,
+                                     float* neg_lse2, hipStream_t stream) {
+  if (num_windows < 0 || channels <= 0 || num_heads <= 0 || channels % num_heads || n_pad < n) return SS_ERR_ARG;
+  if (num_windows == 0) return SS_OK;
+  return ss_attn_hm_fwd(hm, n_pad, sidx, win_start, num_windows, max_window, out, neg_lse2, channels, num_heads, 1.f, stream);
+}
+
+extern "C" size_t ss_window_attn_hm_bwd_workspace_bytes(int64_t n, int64_t n_pad, int channels, int num_heads) {
+  return hm_al256((size_t)n_pad * num_heads * 4) + hm_al256((size_t)n_pad * channels * 2) + hm_al256((size_t)(n_pad - n) * 2 * channels * 2);
+}
+
+extern "C" int ss_window_attn_hm_bwd(const void* hm, const void* out, const void* dout, const float* neg_lse2,
+                                     const int32_t* gidx, const int32_t* sidx, const int32_t* win_start, int num_windows,
+                                     int max_window, int64_t n, int64_t n_pad, int channels, int num_heads, float scale,
+                                     void* dqkv, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (num_windows < 0 || channels <= 0 || num_heads <= 0 || channels % num_heads || n_pad < n) return SS_ERR_ARG;
+  if (workspace_bytes < ss_window_attn_hm_bwd_workspace_bytes(n, n_pad, channels, num_heads)) return SS_ERR_WORKSPACE;
+  if (num_windows == 0) return SS_OK;
+  float* ndelta = (float*)workspace;
+  char* doh = (char*)workspace + hm_al256((size_t)n_pad * num_heads * 4);
+  char* extra = doh + hm_al256((size_t)n_pad * channels * 2);
+  int rc = ss_attn_hm_dq(hm, n_pad, dout, out, neg_lse2, ndelta, doh, sidx, win_start, num_windows, max_window, dqkv, channels,
+                         num_heads, scale, stream);
+  if (rc) return rc;
+  rc = ss_attn_hm_dkv(hm, n_pad, doh, neg_lse2, ndelta, sidx, win_start, num_windows, max_window, dqkv, extra, channels, num_heads,
+                      stream);
+  if (rc) return rc;
+  if (n_pad > n) rc = ss_attn_fix_borrowed(gidx, sidx, n_pad, extra, dqkv, channels, SS_BF16, stream);
+  return rc;
+}

@@ -6,6 +6,10 @@
 //   GATHER = true   submanifold conv forward / dgrad (spconv.SubMConv3d, ptv3:278-284): K = active taps x Cin,
 //                   row(m) = the tap's neighbour of site rowperm[m] (zero row when missing), B = W[co][tap][ci]
 //   GATHER = false  nn.Linear (ptv3 qkv / proj / fc1 / fc2, torch F.linear): row(m) = m
+//   HM              (GATHER = false) the qkv projection in front of the head-major window attention (attention_hm.hip,
+//                   ptv3:172-183): output row m = padded slot m of a curve order, its A row = rowperm[m] (the slot's
+//                   point), and the epilogue writes out[section][head][slot][d] with section 0 (q) multiplied by
+//                   hm_scale = softmax scale * log2(e) in fp32 BEFORE the one bf16 rounding
 //
 // Structure (512 threads = 8 waves as 2 (M) x 4 (N), one workgroup per CU, wave tile 128 x 64):
 //   * LDS: two K-tile buffers (BK = 64) of four 16-KiB HALF-tiles each: A0 A1 B0 B1.  Half h of A holds, for
@@ -57,11 +61,11 @@ __device__ __forceinline__ g8_bf8_t g8_lds(const char* p) {
   return __builtin_bit_cast(g8_bf8_t, *reinterpret_cast<const uint4*>(p));
 }
 
-template <bool GATHER, typename OutT>
+template <bool GATHER, typename OutT, bool HM = false>
 __global__ void __launch_bounds__(512)
 k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, const float* __restrict__ bias,
         const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowperm, OutT* __restrict__ out, int M, int K,
-        int N, int taps, int ntn, int kchunk) {
+        int N, int taps, int ntn, int kchunk, int hm_c = 0, int hm_d = 0, float hm_scale = 1.f) {
   __shared__ __attribute__((aligned(16))) char smem[G8_LDS_BYTES];   // ONE object: tiles + rulebook slice
   int32_t* nbr_s = reinterpret_cast<int32_t*>(smem + G8_OFF_NBR);
   int32_t* rowid_s = reinterpret_cast<int32_t*>(smem + G8_OFF_ROWID);
@@ -130,6 +134,7 @@ k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__
         pA[q] = (src >= 0 ? A + (int64_t)src * K : reinterpret_cast<const unsigned short*>(g8_zero)) + lc8;
       } else {
         int row = min(m0 + R, M - 1);
+        if (HM) row = rowperm[row];
         pA[q] = A + (int64_t)row * K + lc8;
       }
     }
@@ -276,6 +281,11 @@ k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__
           f32x4_t v = acc[ha][mi][hb][ni];
           if (bias) { float4 bv = *reinterpret_cast<const float4*>(bias + col); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
           OutT* op = out + row * N + col;
+          if (HM) {       // (section, head, slot, d): 4 consecutive channels never straddle a head (hm_d % 4 == 0)
+            const int sec = col / hm_c, cc = col - sec * hm_c, hd = cc / hm_d, dd = cc - hd * hm_d;
+            if (sec == 0) { v[0] *= hm_scale; v[1] *= hm_scale; v[2] *= hm_scale; v[3] *= hm_scale; }
+            op = out + (((int64_t)sec * (hm_c / hm_d) + hd) * M + row) * hm_d + dd;
+          }
           if (sizeof(OutT) == 2) {
             uint2 u; u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
             *reinterpret_cast<uint2*>(op) = u;
@@ -325,4 +335,21 @@ extern "C" int ss_linear_fwd(const void* x, const void* weight, const float* bia
                              int out_dtype, hipStream_t stream) {
   if (m == 0) return SS_OK;
   return g8_launch<false>(x, weight, bias, nullptr, nullptr, out, m, k, n, 1, out_dtype, stream);
+}
+
+// qkv projection with the head-major, window-ordered epilogue (see the header): x (n, k) bf16, row_index (m) = the point of
+// padded slot p, weight (n_out, k) bf16 with n_out = sections * channels, out (sections, channels / head_dim, m, head_dim) bf16
+extern "C" int ss_linear_fwd_headmajor(const void* x, const int32_t* row_index, const void* weight, const float* bias,
+                                       void* out_hm, int64_t m, int k, int n_out, int channels, int head_dim,
+                                       float sec0_scale, hipStream_t stream) {
+  if (m == 0) return SS_OK;
+  if (!ss_gemm8_ok(m, k, n_out, 1) || channels <= 0 || head_dim <= 0 || (head_dim & 3) || channels % head_dim || n_out % channels ||
+      !row_index)
+    return SS_ERR_ARG;
+  const int ntm = ss_div_up(m, 256), ntn = ss_div_up(n_out, 256);
+  dim3 grid(ntm * ntn), block(512);
+  SS_LAUNCH((k_gemm8<false, unsigned short, true>), grid, block, 0, stream, (const unsigned short*)x, (const unsigned short*)weight,
+            bias, (const int32_t*)nullptr, row_index, (unsigned short*)out_hm, (int)m, k, n_out, 1, ntn, k, channels, head_dim,
+            sec0_scale);
+  return SS_OK;
 }

@@ -664,37 +664,43 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, dy):
         x, w16 = ctx.saved_tensors
         w_dtype, has_bias = ctx.meta
-        dy = dy.contiguous()
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            # w16 is the (in, out) copy when the layer registered one: hipBLASLt's NT form (functional.register_transposed)
-            dx = torch.nn.functional.linear(dy, w16) if ctx.dgrad_nt else dy @ w16
-        want_db = has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
-            m, k = x.shape
-            if m >= LINEAR_WGRAD_MIN_ROWS and nv.lib().ss_wgrad8_ok(m, k, dy.shape[1], 1):
-                if ctx.stage is not None and w_dtype == torch.float32:
-                    # queued: the stage's identity node launches the whole group when the backward chain leaves the stage
-                    dw, db_ = nv.linear_wgrad_alloc(k, dy.shape[1], want_db, x.device)
-                    ctx.stage.queue.append((x, dy, dw, db_))
-                    if want_db:
-                        db, want_db = db_, False
-                elif _Defer.open and w_dtype == torch.float32:
-                    dw, db_ = nv.linear_wgrad_alloc(k, dy.shape[1], want_db, x.device)
-                    _defer(lambda: nv.linear_wgrad_into(x, dy, dw, db_), (x, dy, dw))
-                    if want_db:
-                        db, want_db = db_, False
-                elif want_db:                    # column sums of dy ride along in the wgrad kernel
-                    dw, db = nv.linear_wgrad(x, dy, True)
-                    dw, db = dw.to(w_dtype), db.to(w_dtype)
-                    want_db = False
-                else:
-                    dw = nv.linear_wgrad(x, dy).to(w_dtype)
-            else:
-                dw = _mm_f32(dy.t(), x).to(w_dtype)     # small levels: library GEMM, fp32 out where aten::mm.dtype exists
-        if want_db:
-            db = dy.sum(0, dtype=torch.float32).to(w_dtype)
+        dx, dw, db = _linear_backward(x, w16, ctx.dgrad_nt, w_dtype, has_bias, ctx.stage, dy.contiguous(), ctx.needs_input_grad[0],
+                                      ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, dw, db, None, None, None, None
+
+
+def _linear_backward(x, w16, dgrad_nt, w_dtype, has_bias, stage, dy, need_x, need_w, need_b):
+    """dx, dW, db of y = x @ W.T + b (the backward of _Linear and of the fused qkv + attention function)."""
+    dx = dw = db = None
+    if need_x:
+        # w16 is the (in, out) copy when the layer registered one: hipBLASLt's NT form (functional.register_transposed)
+        dx = torch.nn.functional.linear(dy, w16) if dgrad_nt else dy @ w16
+    want_db = has_bias and need_b
+    if need_w:
+        m, k = x.shape
+        if m >= LINEAR_WGRAD_MIN_ROWS and nv.lib().ss_wgrad8_ok(m, k, dy.shape[1], 1):
+            if stage is not None and w_dtype == torch.float32:
+                # queued: the stage's identity node launches the whole group when the backward chain leaves the stage
+                dw, db_ = nv.linear_wgrad_alloc(k, dy.shape[1], want_db, x.device)
+                stage.queue.append((x, dy, dw, db_))
+                if want_db:
+                    db, want_db = db_, False
+            elif _Defer.open and w_dtype == torch.float32:
+                dw, db_ = nv.linear_wgrad_alloc(k, dy.shape[1], want_db, x.device)
+                _defer(lambda: nv.linear_wgrad_into(x, dy, dw, db_), (x, dy, dw))
+                if want_db:
+                    db, want_db = db_, False
+            elif want_db:                    # column sums of dy ride along in the wgrad kernel
+                dw, db = nv.linear_wgrad(x, dy, True)
+                dw, db = dw.to(w_dtype), db.to(w_dtype)
+                want_db = False
+            else:
+                dw = nv.linear_wgrad(x, dy).to(w_dtype)
+        else:
+            dw = _mm_f32(dy.t(), x).to(w_dtype)     # small levels: library GEMM, fp32 out where aten::mm.dtype exists
+    if want_db:
+        db = dy.sum(0, dtype=torch.float32).to(w_dtype)
+    return dx, dw, db
 
 
 LINEAR_WGRAD_MIN_ROWS = 1024     # in-process A/B on room-102400: 1024 beats 4096 by 0.5 ms/step
@@ -712,6 +718,76 @@ def linear(x, weight, bias=None):
                                  _STAGE["cur"], bf16_t_of(weight))
         return _Linear.apply(x.to(torch.bfloat16).contiguous(), weight, bias, bf16_of(weight), bf16_of(bias), None, bf16_t_of(weight))
     return torch.nn.functional.linear(x, weight, bias)
+
+
+class _QkvWindowAttentionHM(torch.autograd.Function):
+    """qkv projection + serialized-window attention on the head-major layout (csrc/attention_hm.hip; ptv3:172-216).
+    Forward: the projection writes q / k / v head-major and window-ordered from its own epilogue (gemm8.hip; narrow levels:
+    fp32 library GEMM + ss_headmajor_pack, the same single rounding), the attention kernels stage contiguous tiles by LDS-DMA.
+    Backward: dqkv (n, 3C) in memory row order, then exactly _Linear's dgrad / wgrad paths."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w16, stage, w16t, win, num_heads, scale):
+        sec0 = float(scale) * nv.LOG2E
+        b32 = bias.detach() if bias is not None else None
+        if nv.headmajor_eligible(x.shape[1]) and x.shape[0] >= HM_FUSED_MIN_ROWS and x.shape[1] >= HM_FUSED_MIN_CHANNELS:
+            hm = nv.linear_fwd_headmajor(x, win, w16, b32.float() if b32 is not None else None, num_heads, sec0)
+        else:
+            qkv = _mm_f32(x, w16.t())
+            if b32 is not None:
+                qkv = qkv + b32.float()
+            hm = nv.headmajor_pack(qkv.contiguous(), win, num_heads, 3, sec0)
+        out, nlse2 = nv.window_attn_hm_fwd(hm, win, num_heads)
+        ctx.save_for_backward(x, w16 if w16t is None else w16t, hm, out, nlse2)
+        ctx.meta = (weight.dtype, bias is not None)
+        ctx.dgrad_nt = w16t is not None
+        ctx.stage, ctx.win, ctx.num_heads, ctx.scale = stage, win, num_heads, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w16, hm, out, nlse2 = ctx.saved_tensors
+        w_dtype, has_bias = ctx.meta
+        dqkv = nv.window_attn_hm_bwd(hm, out, dout.contiguous().to(torch.bfloat16), nlse2, ctx.win, ctx.num_heads, ctx.scale)
+        dx, dw, db = _linear_backward(x, w16, ctx.dgrad_nt, w_dtype, has_bias, ctx.stage, dqkv, ctx.needs_input_grad[0],
+                                      ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return dx, dw, db, None, None, None, None, None, None
+
+
+HM_FUSED_MIN_ROWS = int(os.environ.get("SS_HM_FUSED_MIN_ROWS", "4096"))        # below: fp32 library GEMM + pack kernel
+HM_FUSED_MIN_CHANNELS = int(os.environ.get("SS_HM_FUSED_MIN_CHANNELS", "128"))
+
+
+def qkv_window_attention(x, weight, bias, win, num_heads, scale):
+    """SerializedAttention's qkv Linear + attention (ptv3:172-216) under CUDA bf16 autocast, MFMA path: (n, C) -> (n, C)."""
+    route = _STAGE["route"]
+    wr = route.get(id(weight)) if (route and torch.is_grad_enabled()) else None
+    br = route.get(id(bias)) if (wr is not None and bias is not None) else None
+    stage = _STAGE["cur"] if wr is not None else None
+    return _QkvWindowAttentionHM.apply(x.to(torch.bfloat16).contiguous(), wr if wr is not None else weight,
+                                       br if br is not None else bias, bf16_of(weight), stage, bf16_t_of(weight), win, num_heads,
+                                       scale)
+
+
+def window_attention_hm(qkv, win, num_heads, scale):
+    """The head-major kernels behind the (n, 3C) interface of window_attention (tests, narrow callers): pack + attention."""
+    return _WindowAttentionHM.apply(qkv, win, num_heads, scale)
+
+
+class _WindowAttentionHM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, win, num_heads, scale):
+        hm = nv.headmajor_pack(qkv.contiguous(), win, num_heads, 3, float(scale) * nv.LOG2E)
+        out, nlse2 = nv.window_attn_hm_fwd(hm, win, num_heads)
+        ctx.save_for_backward(hm, out, nlse2)
+        ctx.win, ctx.num_heads, ctx.scale, ctx.in_dtype = win, num_heads, scale, qkv.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        hm, out, nlse2 = ctx.saved_tensors
+        dqkv = nv.window_attn_hm_bwd(hm, out, dout.contiguous().to(torch.bfloat16), nlse2, ctx.win, ctx.num_heads, ctx.scale)
+        return dqkv.to(ctx.in_dtype), None, None, None
 
 
 class _LayerNorm(torch.autograd.Function):

@@ -779,3 +779,69 @@ def window_attn_bwd(qkv, out, dout, lse, win, num_heads, scale, impl):
                                    dtype_code(qkv), int(impl), _p(dqkv), _p(ws), ws.numel(), _stream()),
           "ss_window_attn_bwd")
     return dqkv
+
+
+# ---- head-major window attention (csrc/attention_hm.hip, round 3) ------------------------------------------------------
+LOG2E = 1.4426950408889634
+
+
+def headmajor_eligible(k):
+    """The projection can write the head-major layout from its own epilogue (gemm8.hip) when k is a multiple of 64."""
+    return k >= 64 and k % 64 == 0
+
+
+def linear_fwd_headmajor(x, win, w, bias, num_heads, sec0_scale):
+    """hm (sections, H, n_pad, D) bf16 = head-major, window-ordered x[gidx] @ w.T + bias; section 0 times sec0_scale (fp32,
+    before the one bf16 rounding).  x (n, k) bf16, w (sections * C, k) bf16, bias (sections * C) f32 or None."""
+    n, k = x.shape
+    nout = w.shape[0]
+    _req(x, torch.bfloat16, "x"); _req(w, torch.bfloat16, "weight", (nout, k))
+    if bias is not None:
+        _req(bias, torch.float32, "bias", (nout,))
+    if n != win.n:
+        raise RuntimeError(f"x rows {n} != window index rows {win.n}")
+    C = k
+    if nout % C:
+        raise RuntimeError("output width must be a multiple of the channel count")
+    hm = torch.empty((nout // C, num_heads, win.n_pad, C // num_heads), dtype=torch.bfloat16, device=x.device)
+    check(lib().ss_linear_fwd_headmajor(_p(x), _p(win.gidx), _p(w), _p(bias), _p(hm), win.n_pad, k, nout, C, C // num_heads,
+                                        float(sec0_scale), _stream()), "ss_linear_fwd_headmajor")
+    return hm
+
+
+def headmajor_pack(src, win, num_heads, sections, sec0_scale):
+    """hm (sections, H, n_pad, D) bf16 from an (n, sections * C) projection (fp32 or bf16) in memory row order."""
+    n, w = src.shape
+    _req(src, None, "src")
+    C = w // sections
+    hm = torch.empty((sections, num_heads, win.n_pad, C // num_heads), dtype=torch.bfloat16, device=src.device)
+    check(lib().ss_headmajor_pack(_p(src), dtype_code(src), _p(win.gidx), _p(hm), win.n_pad, C, num_heads, sections,
+                                  float(sec0_scale), _stream()), "ss_headmajor_pack")
+    return hm
+
+
+def window_attn_hm_fwd(hm, win, num_heads):
+    _req(hm, torch.bfloat16, "hm")
+    sections, H, n_pad, D = hm.shape
+    if sections != 3 or H != num_heads or n_pad != win.n_pad:
+        raise RuntimeError(f"hm shape {tuple(hm.shape)} does not match the window index (n_pad {win.n_pad}, heads {num_heads})")
+    C = H * D
+    out = torch.empty((win.n, C), dtype=torch.bfloat16, device=hm.device)
+    nlse2 = torch.empty((H, n_pad), dtype=torch.float32, device=hm.device)
+    check(lib().ss_window_attn_hm_fwd(_p(hm), _p(win.sidx), _p(win.win_start), win.num_windows, win.max_window, win.n, n_pad, C,
+                                      H, _p(out), _p(nlse2), _stream()), "ss_window_attn_hm_fwd")
+    return out, nlse2
+
+
+def window_attn_hm_bwd(hm, out, dout, nlse2, win, num_heads, scale):
+    sections, H, n_pad, D = hm.shape
+    C = H * D
+    _req(out, torch.bfloat16, "out", (win.n, C)); _req(dout, torch.bfloat16, "dout", (win.n, C))
+    _req(nlse2, torch.float32, "nlse2", (H, n_pad))
+    dqkv = torch.empty((win.n, 3 * C), dtype=torch.bfloat16, device=hm.device)
+    nb = lib().ss_window_attn_hm_bwd_workspace_bytes(win.n, n_pad, C, H)
+    ws = _ws(nb, hm.device)
+    check(lib().ss_window_attn_hm_bwd(_p(hm), _p(out), _p(dout), _p(nlse2), _p(win.gidx), _p(win.sidx), _p(win.win_start),
+                                      win.num_windows, win.max_window, win.n, n_pad, C, H, float(scale), _p(dqkv), _p(ws),
+                                      ws.numel(), _stream()), "ss_window_attn_hm_bwd")
+    return dqkv

@@ -30,6 +30,7 @@ from .structure import Point
 
 # knobs of the execution (not of the model): attention kernel family and conv compute dtype
 RUNTIME = dict(attn_impl=nv.ATTN_SIMT, conv_dtype=None,  # conv_dtype: None = fp32 per-tap path (reference), torch.bfloat16, or "bf16x3"
+               attn_headmajor=os.environ.get("SS_ATTN_HM", "1") != "0",   # MFMA attention on the head-major layout (round 3)
                param_shadows=os.environ.get("SS_PARAM_SHADOWS", "1") != "0")   # bf16 weight shadows under autocast
 
 
@@ -114,8 +115,14 @@ class SerializedAttention(PointModule):
 
     def forward(self, x, level):
         win = level.window(self.order_index, self.patch_size)
-        qkv = _lin(self.qkv, x)
         impl = RUNTIME["attn_impl"]
+        if (impl == nv.ATTN_MFMA and RUNTIME.get("attn_headmajor", True) and x.is_cuda and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and self.qkv.weight.dtype == torch.float32
+                and (self.channels // self.num_heads) in (16, 32, 48, 64)):
+            # round 3: projection -> head-major, window-ordered q / k / v -> LDS-DMA attention kernels (csrc/attention_hm.hip)
+            feat = SF.qkv_window_attention(x, self.qkv.weight, self.qkv.bias, win, self.num_heads, self.scale)
+            return _lin(self.proj, feat)
+        qkv = _lin(self.qkv, x)
         if impl == nv.ATTN_MFMA and qkv.dtype != torch.bfloat16:
             feat = SF.window_attention(qkv.to(torch.bfloat16), win, self.num_heads, self.scale, impl).to(qkv.dtype)
         else:
