@@ -18,6 +18,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# before torch is imported and long before any GPU call: the host driver only supports dmabuf IPC (RCCL / tensor sharing across
+# processes fails otherwise), and the HSA runtime reads the variable once, when it initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -278,7 +281,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:

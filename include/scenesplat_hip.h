@@ -82,6 +82,10 @@ int ss_window_attn_bwd(const void* qkv, const void* out, const void* dout, const
                        int64_t n_pad, int channels, int num_heads, float scale, int dtype, int impl, void* dqkv,
                        void* workspace, size_t workspace_bytes, ss_stream_t stream);
 
+/* ---- runtime queries -------------------------------------------------------------------- */
+/* 0 = the stream is not capturing, 1 = capturing, 2 = its capture was invalidated (abandon it: never end it), < 0 = query failed */
+int ss_stream_capture_status(ss_stream_t stream);
+
 /* ---- head-major window attention (round 3) ------------------------------------------------------------
  * hm (sections = 3, num_heads, n_pad, head_dim) bf16: q / k / v of padded slot p of the curve order (slot p = point gidx[p]);
  * section 0 holds q * softmax_scale * log2(e).  Written by ss_linear_fwd_headmajor (the projection itself, LDS-DMA pipeline

@@ -1,0 +1,12 @@
+// Small runtime queries of the C-ABI that have no kernel behind them.
+#include "common.h"
+#include "../../include/scenesplat_hip.h"
+
+// Capture status of a HIP stream: 0 = not capturing, 1 = capturing, 2 = capture invalidated (an illegal call was made while the
+// stream captured: the capture can only be abandoned; ending it crashes inside the runtime on this stack).  < 0: the query failed.
+extern "C" int ss_stream_capture_status(hipStream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  hipError_t e = hipStreamIsCapturing(stream, &st);
+  if (e != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return st == hipStreamCaptureStatusNone ? 0 : (st == hipStreamCaptureStatusActive ? 1 : 2);
+}

@@ -408,7 +408,9 @@ def refresh_shadows(src, dst):
         if everything or ent is None or ent[0] is not d or ent[1] != st:
             todo_s.append(p); todo_d.append(d)
             if ent is not None and ent[0] is d:
-                ent[1] = st
+                # while capturing the copy is only RECORDED (it runs at replay): leave the shadow marked stale, so that an
+                # eager step after a refused capture re-casts instead of trusting weights one optimizer step old
+                ent[1] = None if everything else st
     if todo_s:
         torch._foreach_copy_(todo_d, todo_s)
         pairs = [(d, _SHADOW_T[p]) for p, d in zip(todo_s, todo_d) if p in _SHADOW_T]

@@ -845,3 +845,9 @@ def window_attn_hm_bwd(hm, out, dout, nlse2, win, num_heads, scale):
                                       win.num_windows, win.max_window, win.n, n_pad, C, H, float(scale), _p(dqkv), _p(ws),
                                       ws.numel(), _stream()), "ss_window_attn_hm_bwd")
     return dqkv
+
+
+def stream_capture_status(stream=None):
+    """0 = not capturing, 1 = capturing, 2 = the capture was invalidated (it must be abandoned, never ended), -1 = unknown."""
+    st = stream if stream is not None else torch.cuda.current_stream()
+    return int(lib().ss_stream_capture_status(ctypes.c_void_p(st.cuda_stream)))

@@ -370,7 +370,18 @@ class Trainer(TrainerBase):
             self._steady = SteadyStateStep(fwd_bwd, [p for p in model.parameters() if p.requires_grad], warmup=1)
         tensors = {k: v for k, v in inp.items() if isinstance(v, torch.Tensor) and v.is_cuda}
         self._steady_host = {k: v for k, v in inp.items() if k not in tensors}
-        key = tuple(sorted((k, repr(v)) for k, v in self._steady_host.items() if isinstance(v, (int, float, bool, str, type(None)))))
+        # the key holds the host DECISIONS of the step: the model's own summary when it has one (LangPretrainer.steady_key: the
+        # schedule gates, not the epoch_progress float, which would re-capture every epoch), every other host scalar and
+        # list / tuple of scalars verbatim
+        def _hashable(v):
+            if isinstance(v, (int, float, bool, str, type(None))):
+                return repr(v)
+            if isinstance(v, (list, tuple)) and all(isinstance(e, (int, float, bool, str, type(None))) for e in v):
+                return repr(tuple(v))
+            return None
+        own = model.steady_key(self._steady_host) if hasattr(model, "steady_key") else None
+        skip = {"epoch_progress"} if own is not None else set()
+        key = (own,) + tuple(sorted((k, _hashable(v)) for k, v in self._steady_host.items() if k not in skip and _hashable(v) is not None))
         plan = backbone.prepare_plan(inp)
         self.optimizer.zero_grad(set_to_none=True)
         return self._steady(plan, tensors, key=(key, bool(model.training)))
@@ -382,7 +393,7 @@ class Trainer(TrainerBase):
                 inp[k] = v.to(self.device, non_blocking=True)
         amp = bool(self.cfg.get("enable_amp")) and self.device.type == "cuda"
         if (self.cfg.get("steady_state") and self.device.type == "cuda" and get_world_size() == 1
-                and hasattr(getattr(self.model, "backbone", self.model), "prepare_plan")):
+                and hasattr(getattr(self.model, "backbone", self.model), "prepare_plan") and "grid_coord" in inp):
             inp["epoch_progress"] = self.epoch / self.max_epoch
             out = self._steady_run_step(inp, amp)
             if self.cfg.get("clip_grad") is not None:

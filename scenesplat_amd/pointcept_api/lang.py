@@ -173,6 +173,20 @@ class LangPretrainer(nn.Module):
         self.backbone = build_model(backbone)
         self.criteria = build_criteria(criteria)
 
+    def steady_key(self, host):
+        """The HOST-side decisions a training step of this model takes, as a hashable key for the steady-state replay
+        (scenesplat_amd/steady_state.py): the schedule gate of every criterion, not the raw epoch_progress float (which changes
+        every epoch and would force a re-capture per epoch)."""
+        ep = host.get("epoch_progress", None)
+        gates = []
+        for c in self.criteria.criteria:
+            sched = getattr(c, "schedule", None)
+            if isinstance(sched, str) and "last_" in sched and ep is not None:
+                gates.append(bool(ep > (1 - c.last_percent)))
+            else:
+                gates.append(sched)
+        return tuple(gates)
+
     def forward(self, input_dict, chunk_size=None):
         if chunk_size is not None and chunk_size > 0 and input_dict["coord"].shape[0] > chunk_size:
             return self._chunked_forward(input_dict, chunk_size)

@@ -35,6 +35,15 @@ class _Captured:
     __slots__ = ("graph", "plan", "inputs", "outputs", "grads", "keep")
 
 
+class CaptureInvalidated(RuntimeError):
+    """A hipGraph capture was invalidated half way (an illegal call while the stream captured).  Such a capture cannot be ended
+    -- capture_end() on it crashes inside the runtime -- so it is abandoned, every replay path of the step is switched off and
+    this error travels to the caller instead of a silent eager retry on a stream in an unknown state."""
+
+
+_ABANDONED = []     # graph objects of invalidated captures: kept alive so that nothing ever calls into them again
+
+
 class SteadyStateStep:
     """step = SteadyStateStep(fn, params); out = step(plan, {"feat": ..., ...})
 
@@ -48,7 +57,9 @@ class SteadyStateStep:
         self.fn, self.params = fn, list(params)
         self.warmup, self.max_graphs, self.enabled = int(warmup), int(max_graphs), bool(enabled)
         self._seen, self._graphs = {}, {}
-        self.refused = None            # repr of the exception that ended a capture: eager from then on
+        self._refused = {}             # signature -> repr of what refused its capture: THAT signature runs eagerly from then on
+        self.refused = None            # the most recent refusal (None: none so far)
+        self.poisoned = None           # set when a capture was invalidated: no further capture is attempted by this object
         self._checked = set()          # signatures whose eager step passed the sync check (every new signature is checked: a host-side
                                        # key may open a branch that reads values on the host)
         self.replays = self.eager_steps = 0
@@ -65,9 +76,11 @@ class SteadyStateStep:
     def __call__(self, plan, inputs, key=None):
         """key: hashable summary of every HOST-side value the step's control flow depends on (a loss schedule gate, a mode
         flag): a captured graph is replayed only for the key it was captured under."""
-        if not self.enabled or self.refused is not None:
+        if not self.enabled or self.poisoned is not None:
             return self._eager(plan, inputs)
         sig = self._signature(plan, inputs, key)
+        if sig in self._refused:
+            return self._eager(plan, inputs)
         cap = self._graphs.get(sig)
         if cap is None:
             if len(self._seen) > 256:                          # batches of ever-changing shape: forget the counts
@@ -98,14 +111,19 @@ class SteadyStateStep:
                 except Exception as e:  # noqa: BLE001
                     torch.cuda.set_sync_debug_mode("default")
                     main.wait_stream(side)
-                    self._refuse(e)
+                    self._refuse(e, sig)
                     return self._eager(plan, inputs)
                 finally:
                     torch.cuda.set_sync_debug_mode("default")
             try:
                 cap = self._capture(plan, inputs)
-            except Exception as e:  # noqa: BLE001 -- whatever refused the capture, the eager step still works
-                self._refuse(e)
+            except CaptureInvalidated as e:
+                # no device-wide synchronisation here: this thread still owns the (dead) capture, the runtime would refuse it
+                self.poisoned = repr(e)
+                self._refuse(e, sig, sync=False)
+                raise
+            except Exception as e:  # noqa: BLE001 -- the capture was still valid and has been ended: the eager step works
+                self._refuse(e, sig)
                 return self._eager(plan, inputs)
             self._graphs[sig] = cap
             while len(self._graphs) > self.max_graphs:
@@ -121,12 +139,17 @@ class SteadyStateStep:
         self.replays += 1
         return cap.outputs
 
-    def _refuse(self, exc):
+    def _refuse(self, exc, sig=None, sync=True):
         self.refused = repr(exc)
+        if sig is not None:
+            if len(self._refused) > 256:
+                self._refused.clear()
+            self._refused[sig] = self.refused
         SF.reset_state()
         for p in self.params:
             p.grad = None
-        torch.cuda.synchronize()
+        if sync:
+            torch.cuda.synchronize()
 
     def _capture(self, plan, inputs):
         cap = _Captured()
@@ -146,21 +169,29 @@ class SteadyStateStep:
         torch.cuda.synchronize()
         nv.CAPTURE_POOL = cap.keep
         try:
-            # capture_begin / capture_end by hand (not `with torch.cuda.graph`): when the step raises, the capture is still
-            # ended and the stream context restored before the exception travels on
+            # capture_begin / capture_end by hand (not `with torch.cuda.graph`).  thread_local error mode: HIP calls of OTHER
+            # threads (a pin-memory thread, a plan build on its own stream) no longer invalidate this capture.  When the step
+            # raises, the capture is ended ONLY while the runtime still reports it active: ending an invalidated capture is the
+            # call that crashed the process in round 2 (Fatal Python error in capture_end after hipErrorStreamCaptureImplicit).
             with torch.cuda.stream(side):
-                cap.graph.capture_begin()
+                cap.graph.capture_begin(capture_error_mode="thread_local")
                 try:
                     cap.outputs = {k: v.detach() for k, v in self.fn(cap.plan, cap.inputs).items()}
-                except BaseException:
+                except BaseException as e:
                     if os.environ.get("SS_STEADY_DEBUG"):
                         import traceback
                         traceback.print_exc()
-                    try:
-                        cap.graph.capture_end()
-                    except Exception:  # noqa: BLE001 -- an invalidated capture reports its error once more here
-                        pass
-                    raise
+                    status = nv.stream_capture_status(side)
+                    if status == 1:
+                        cap.graph.capture_end()          # a Python-level error inside a healthy capture: end it, drop the graph
+                        raise
+                    # invalidated (2) or unknown: abandon the graph object WITHOUT ending / resetting it (its destructor does
+                    # not touch the stream) and surface the original error
+                    _ABANDONED.append(cap.graph)
+                    raise CaptureInvalidated(f"hipGraph capture invalidated (status {status}) by: {e!r}") from e
+                if nv.stream_capture_status(side) != 1:
+                    _ABANDONED.append(cap.graph)
+                    raise CaptureInvalidated("hipGraph capture invalidated by a call inside the step (no Python error)")
                 cap.graph.capture_end()
         finally:
             nv.CAPTURE_POOL = None

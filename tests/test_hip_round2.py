@@ -528,6 +528,38 @@ def test_steady_state_falls_back_to_eager_on_other_shapes_and_refused_captures()
         assert steady.replays == 2 and torch.isfinite(out.float()).all()
 
 
+def test_steady_state_error_inside_a_capture_falls_back_to_eager_with_fresh_weights():
+    """A step that raises ONLY while its stream captures (round-2 advisor finding): the capture is still healthy, so it is
+    ended, that signature is refused (others are not), and the eager fallback runs on CURRENT weights -- an optimizer step taken
+    before the failing capture must not be hidden by bf16 shadows stamped during the capture."""
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.steady_state import SteadyStateStep
+    with _Runtime(conv_dtype=torch.bfloat16, attn_impl=nv.ATTN_MFMA):
+        model, d, n, fn = _steady_setup()
+        cot = torch.randn(n, TINY["dec_channels"][0], device="cuda").to(torch.bfloat16)
+
+        def failing(plan, t):
+            r = fn(plan, t)
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("injected failure inside the capture")
+            return r
+        steady = SteadyStateStep(failing, model.parameters(), warmup=0)
+        steady(model.prepare_plan(d), dict(feat=d["feat"], cot=cot))          # the sync-checked eager step
+        with torch.no_grad():                                                  # "optimizer step" before the capture is attempted
+            for p in model.parameters():
+                p.mul_(1.05)
+        out = steady(model.prepare_plan(d), dict(feat=d["feat"], cot=cot))["feat"].float()
+        assert steady.refused is not None and "injected" in steady.refused and steady.poisoned is None and steady.replays == 0
+        assert nv.stream_capture_status() == 0
+        # the fallback equals a plain eager step on the current weights
+        for p in model.parameters():
+            p.grad = None
+        ref = fn(model.prepare_plan(d), dict(feat=d["feat"], cot=cot))["feat"].detach().float()
+        assert float((out - ref).norm() / ref.norm()) < 1e-3
+        out2 = steady(model.prepare_plan(d), dict(feat=d["feat"], cot=cot))["feat"].float()      # refused signature: eager from now on
+        assert steady.replays == 0 and torch.isfinite(out2).all()
+
+
 def test_steady_state_replays_draw_fresh_droppath_masks():
     """DropPath inside a replayed graph: the Philox offset of the default generator advances per replay (torch registers
     the generator with the capture), so two replays on the SAME inputs differ -- and equal inputs with drop_path = 0 do not."""
