@@ -41,15 +41,20 @@ def _take_rows(t, idx32):
     return t[idx32.long()]
 
 
+# the per-point entries SphereCrop crops (transform.py:1511-1546); every other entry of the dict is passed through untouched
+SPHERE_CROP_KEYS = ("coord", "origin_coord", "grid_coord", "color", "quat", "scale", "opacity", "normal", "lang_feat",
+                    "valid_feat_mask", "segment", "instance", "displacement", "strength")
+
+
 @torch.no_grad()
-def sphere_crop(data_dict, point_max=80000, sample_rate=None, mode="random", generator=None):
+def sphere_crop(data_dict, point_max=80000, sample_rate=None, mode="random", generator=None, center_index=None, extra_keys=()):
     """SphereCrop(mode="random" | "center") on the device (pointcept/datasets/transform.py:1420-1548): when the sample has
     more than point_max points keep the point_max points nearest to a centre point -- a uniformly random point, or the
     middle row -- in ascending distance order (ties by row index).  The distance sort is the library's stable radix
     argsort on the float bit pattern (squared distances are non-negative, so the IEEE bits are order-preserving).
-    Every per-point tensor of the dict (first dimension N) is cropped; the reference enumerates the SceneSplat keys
-    coord / origin_coord / grid_coord / color / quat / scale / opacity / normal / lang_feat / valid_feat_mask / segment /
-    instance / displacement / strength, which are exactly the per-point entries its datasets produce."""
+    Cropped: exactly the keys the reference enumerates (SPHERE_CROP_KEYS) plus `extra_keys`; anything else -- also a tensor
+    whose first dimension happens to equal N -- is passed through, as in the reference.  center_index overrides the random
+    draw (replaying a recorded centre: tests/golden/transforms.npz)."""
     if mode not in ("random", "center"):
         raise NotImplementedError('sphere_crop: mode must be "random" or "center" (mode "all" is the tester\'s CPU fragment loop)')
     coord = data_dict["coord"]
@@ -59,7 +64,9 @@ def sphere_crop(data_dict, point_max=80000, sample_rate=None, mode="random", gen
     pm = int(sample_rate * n) if sample_rate is not None else int(point_max)
     if n <= pm:
         return data_dict
-    if mode == "random":
+    if center_index is not None:
+        ci = int(center_index)
+    elif mode == "random":
         ci = int(torch.randint(0, n, (1,), generator=generator, device=coord.device if generator is not None and generator.device.type == "cuda" else "cpu"))
     else:
         ci = n // 2
@@ -68,8 +75,11 @@ def sphere_crop(data_dict, point_max=80000, sample_rate=None, mode="random", gen
     order, _, _ = nv.argsort_i64(key, 32, want_inverse=False, want_sorted=False)
     idx = order[0, :pm].contiguous()
     out = dict(data_dict)
-    for k, v in data_dict.items():
-        if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == n:
+    for k in tuple(SPHERE_CROP_KEYS) + tuple(extra_keys):
+        v = data_dict.get(k)
+        if isinstance(v, torch.Tensor):
+            if v.shape[0] != n:
+                raise ValueError(f"sphere_crop: '{k}' has {v.shape[0]} rows, coord has {n}")
             out[k] = _take_rows(v, idx)
     return out
 

@@ -81,3 +81,8 @@ def full_inputs():
     quat = torch.nn.functional.normalize(torch.randn(n, 4, generator=g), dim=1)
     scale = torch.rand(n, 3, generator=g) * 1.5
     return gc, torch.cat([color, opacity, quat, scale], 1)
+
+
+def full_cotangent(n, seed=17):
+    """Seeded cotangent of the full-size backward fixture (ptv3_lang_full_bwd.npz): d loss / d feat, (n, 768)."""
+    return torch.randn(n, 768, generator=torch.Generator().manual_seed(seed))

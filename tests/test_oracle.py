@@ -262,3 +262,45 @@ def test_prod_lang_ptv3_matches_reference(golden_dir, mode):
     assert _rel(feat.grad, fx[f"{mode}_dfeat"]) < 2e-3
     for k in mp.GRAD_KEYS:
         assert _rel(mp.proj(sd[k].grad), fx[f"{mode}_grad_proj_{k}"]) < 3e-3, k
+
+
+def _tf_sample(n, seed):
+    g = np.random.RandomState(seed)
+    coord = (g.rand(n, 3) * np.array([4.0, 3.0, 1.5])).astype(np.float32)
+    return dict(coord=coord, color=(g.rand(n, 3) * 2 - 1).astype(np.float32), opacity=g.rand(n, 1).astype(np.float32),
+                quat=g.randn(n, 4).astype(np.float32), scale=g.rand(n, 3).astype(np.float32),
+                segment=g.randint(-1, 20, n).astype(np.int64), lang_feat=g.randn(n, 16).astype(np.float32),
+                valid_feat_mask=(g.rand(n) < 0.9).astype(np.int64), name="scene%d" % seed)
+
+
+def test_transform_restatements_match_the_reference_transforms(golden_dir):
+    """oracle/transforms.py against what the reference's GridSample / SphereCrop / Collect / point_collate_fn produced
+    (tests/golden/transforms.npz, generated by importing pointcept/datasets/transform.py and datasets/utils.py)."""
+    from oracle import transforms as otf
+    fx = load(golden_dir, "transforms.npz")
+    # GridSample: occupied voxels, the point -> voxel partition (the reference numbers voxels by hash rank)
+    d = _tf_sample(int(fx["gs_n"]), int(fx["gs_seed"]))
+    gc, uniq, inv, cnt = otf.grid_sample_voxels(d["coord"], float(fx["gs_grid"]))
+    assert np.array_equal(uniq.astype(np.int32), fx["gs_grid_coord_sorted"]) and len(uniq) == int(fx["gs_n_out"])
+    ref_inv = fx["gs_inverse"]
+    pairs = np.unique(np.stack([inv, ref_inv], 1), axis=0)
+    assert len(pairs) == len(uniq)                                   # the two numberings are a bijection: same partition
+    # SphereCrop
+    d = _tf_sample(int(fx["sc_n"]), int(fx["sc_seed"]))
+    pm = int(fx["sc_point_max"])
+    idx = otf.sphere_crop_index(d["coord"], pm, len(d["coord"]) // 2)
+    assert np.array_equal(d["coord"][idx], fx["sc_center_coord"]) and np.array_equal(d["segment"][idx], fx["sc_center_segment"])
+    assert np.array_equal(d["lang_feat"][idx], fx["sc_center_lang"])
+    idx = otf.sphere_crop_index(d["coord"], pm, int(fx["sc_random_center_index"]))
+    assert np.array_equal(d["coord"][idx], fx["sc_random_coord"]) and np.array_equal(d["opacity"][idx], fx["sc_random_opacity"])
+    idx = otf.sphere_crop_index(d["coord"], int(0.25 * len(d["coord"])), len(d["coord"]) // 2)
+    assert np.array_equal(d["coord"][idx], fx["sc_rate_coord"])
+    # Collect
+    d = _tf_sample(int(fx["co_n"]), int(fx["co_seed"]))
+    d["grid_coord"] = np.floor(d["coord"] / 0.02).astype(np.int64)
+    out = otf.collect(d, ("coord", "grid_coord", "segment", "lang_feat", "valid_feat_mask", "name"), feat_keys=("color", "opacity", "quat", "scale"))
+    assert sorted(out.keys()) == list(fx["co_keys"]) and np.array_equal(out["feat"], fx["co_feat"]) and np.array_equal(out["offset"], fx["co_offset"])
+    # collate
+    assert np.array_equal(otf.collate_offsets(fx["pc_sizes"]), fx["pc_offset"])
+    assert np.array_equal(otf.collate_offsets(fx["pc_sizes"], mix=True), fx["pc_mix_offset"])
+    assert np.array_equal(otf.collate_offsets(fx["pc_sizes"][:3], mix=True), fx["pc_mix_offset_odd"])
