@@ -426,7 +426,9 @@ def main():
             res["roofline_conv_wgrad"] = rl["conv_wgrad"]
             res["roofline_attn"] = rl["attn_fwd"]             # the kernel the north star names
             res["roofline_attn_bwd"] = rl["attn_bwd"]
-            res["roofline_hbm"] = rl["gather_hbm"]            # gather/scatter family on a working set far beyond the Infinity Cache
+            res["roofline_hbm"] = rl["unpool_fwd"]            # gather / scatter kernels THE STEP runs (dec0 unpooling seam): forward ...
+            res["roofline_hbm_bwd"] = rl["unpool_bwd"]        # ... and backward (the grid-pool scatter the north star names)
+            res["roofline_hbm_gather"] = rl["gather_hbm"]     # the row-gather kernel on a working set far beyond the Infinity Cache
             res["roofline_scan"] = rl["scan"]
             del rl
             gc.collect(); torch.cuda.empty_cache()

@@ -197,10 +197,105 @@ __global__ void k_gather_add(const T* __restrict__ a, const T* __restrict__ b, c
   ElemIO<T>::store(dst + gid, v);
 }
 
+// ---- 16-byte-lane forms of the three kernels the step runs at every pooling / unpooling seam (round 3) -------------------
+// One thread per 16-byte chunk of a row (8 bf16 / 4 fp32), fp32 accumulate: every load and store is a dwordx4 and the chunks of a
+// row are adjacent lanes (the one-element-per-thread forms above moved 2 bytes per lane: 0.14-0.26 of the HBM roof at dec0,
+// profiles/r02_kernel_stats.md).  Used whenever the row is a multiple of 16 bytes and the pointers are 16-byte aligned.
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec16<unsigned short> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const unsigned short* p, float (&v)[8]) {
+    uint4 t = *reinterpret_cast<const uint4*>(p);
+    const unsigned int* u = reinterpret_cast<const unsigned int*>(&t);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(u[i] << 16); v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
+  }
+  static __device__ __forceinline__ void store(unsigned short* p, const float (&v)[8]) {
+    uint4 t;
+    t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]); t.z = pack_bf16x2(v[4], v[5]); t.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = t;
+  }
+};
+template <typename T>
+__global__ void k_segment_reduce_v(const T* __restrict__ src, const int32_t* __restrict__ indices, const int32_t* __restrict__ ptr,
+                                   T* __restrict__ out, int64_t n_seg, int C, int chunks, int mean) {
+  constexpr int N = Vec16<T>::N;
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_seg * chunks) return;
+  const int64_t s = gid / chunks; const int c = (int)(gid - s * chunks) * N;
+  const int b = ptr[s], e = ptr[s + 1];
+  float acc[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc[i] = 0.f;
+  for (int j = b; j < e; ++j) {
+    const int64_t r = indices ? indices[j] : j;
+    float v[N];
+    Vec16<T>::load(src + r * C + c, v);
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] += v[i];
+  }
+  if (mean && e > b) {
+    const float inv = (float)(e - b);
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] /= inv;
+  }
+  Vec16<T>::store(out + s * C + c, acc);
+}
+template <typename T>
+__global__ void k_segment_bcast_v(const T* __restrict__ dout, const int32_t* __restrict__ cluster, const int32_t* __restrict__ ptr,
+                                  T* __restrict__ dsrc, int64_t n, int C, int chunks, int mean) {
+  constexpr int N = Vec16<T>::N;
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * chunks) return;
+  const int64_t i = gid / chunks; const int c = (int)(gid - i * chunks) * N;
+  const int s = cluster[i];
+  float v[N];
+  Vec16<T>::load(dout + (int64_t)s * C + c, v);
+  if (mean) {
+    const float cnt = (float)(ptr[s + 1] - ptr[s]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] /= cnt;
+  }
+  Vec16<T>::store(dsrc + i * C + c, v);
+}
+template <typename T>
+__global__ void k_gather_add_v(const T* __restrict__ a, const T* __restrict__ b, const int32_t* __restrict__ idx, T* __restrict__ dst,
+                               int64_t n, int C, int chunks) {
+  constexpr int N = Vec16<T>::N;
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * chunks) return;
+  const int64_t i = gid / chunks; const int c = (int)(gid - i * chunks) * N;
+  float x[N], y[N];
+  Vec16<T>::load(a + i * C + c, x);
+  Vec16<T>::load(b + (int64_t)idx[i] * C + c, y);
+#pragma unroll
+  for (int k = 0; k < N; ++k) x[k] += y[k];
+  Vec16<T>::store(dst + i * C + c, x);
+}
+static inline bool rows_vec16_ok(const void* a, const void* b, const void* c, int channels, int dtype) {
+  const int64_t rb = (int64_t)channels * (dtype == SS_F32 ? 4 : 2);
+  return (rb & 15) == 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
+}
+
 extern "C" int ss_segment_reduce(const void* src, const int32_t* indices, const int32_t* idx_ptr, void* out,
                                  int64_t n_seg, int channels, int dtype, int mean, hipStream_t stream) {
   if (n_seg < 0 || channels <= 0) return SS_ERR_ARG;
   if (n_seg == 0) return SS_OK;
+  if (rows_vec16_ok(src, out, nullptr, channels, dtype)) {
+    const int chunks = channels / (dtype == SS_F32 ? 4 : 8);
+    dim3 gv(ss_div_up(n_seg * chunks, 256)), bv(256);
+    if (dtype == SS_F32)
+      SS_LAUNCH(k_segment_reduce_v<float>, gv, bv, 0, stream, (const float*)src, indices, idx_ptr, (float*)out, n_seg, channels, chunks, mean);
+    else if (dtype == SS_BF16)
+      SS_LAUNCH(k_segment_reduce_v<unsigned short>, gv, bv, 0, stream, (const unsigned short*)src, indices, idx_ptr, (unsigned short*)out, n_seg, channels, chunks, mean);
+    else return SS_ERR_ARG;
+    return SS_OK;
+  }
   dim3 g(ss_div_up(n_seg * channels, 256)), b(256);
   if (dtype == SS_F32)
     SS_LAUNCH(k_segment_reduce<float>, g, b, 0, stream, (const float*)src, indices, idx_ptr, (float*)out, n_seg, channels, mean);
@@ -238,6 +333,16 @@ extern "C" int ss_segment_bcast(const void* dout, const int32_t* cluster, const 
                                 int channels, int dtype, int mean, hipStream_t stream) {
   if (n < 0 || channels <= 0) return SS_ERR_ARG;
   if (n == 0) return SS_OK;
+  if (rows_vec16_ok(dout, dsrc, nullptr, channels, dtype)) {
+    const int chunks = channels / (dtype == SS_F32 ? 4 : 8);
+    dim3 gv(ss_div_up(n * chunks, 256)), bv(256);
+    if (dtype == SS_F32)
+      SS_LAUNCH(k_segment_bcast_v<float>, gv, bv, 0, stream, (const float*)dout, cluster, idx_ptr, (float*)dsrc, n, channels, chunks, mean);
+    else if (dtype == SS_BF16)
+      SS_LAUNCH(k_segment_bcast_v<unsigned short>, gv, bv, 0, stream, (const unsigned short*)dout, cluster, idx_ptr, (unsigned short*)dsrc, n, channels, chunks, mean);
+    else return SS_ERR_ARG;
+    return SS_OK;
+  }
   dim3 g(ss_div_up(n * channels, 256)), b(256);
   if (dtype == SS_F32)
     SS_LAUNCH(k_segment_bcast<float>, g, b, 0, stream, (const float*)dout, cluster, idx_ptr, (float*)dsrc, n, channels, mean);
@@ -251,6 +356,16 @@ extern "C" int ss_gather_add_rows(const void* a, const void* b, const int32_t* i
                                   int dtype, hipStream_t stream) {
   if (n < 0 || channels <= 0) return SS_ERR_ARG;
   if (n == 0) return SS_OK;
+  if (rows_vec16_ok(a, b, dst, channels, dtype)) {
+    const int chunks = channels / (dtype == SS_F32 ? 4 : 8);
+    dim3 gv(ss_div_up(n * chunks, 256)), bv(256);
+    if (dtype == SS_F32)
+      SS_LAUNCH(k_gather_add_v<float>, gv, bv, 0, stream, (const float*)a, (const float*)b, idx, (float*)dst, n, channels, chunks);
+    else if (dtype == SS_BF16)
+      SS_LAUNCH(k_gather_add_v<unsigned short>, gv, bv, 0, stream, (const unsigned short*)a, (const unsigned short*)b, idx, (unsigned short*)dst, n, channels, chunks);
+    else return SS_ERR_ARG;
+    return SS_OK;
+  }
   dim3 g(ss_div_up(n * channels, 256)), bl(256);
   if (dtype == SS_F32)
     SS_LAUNCH(k_gather_add<float>, g, bl, 0, stream, (const float*)a, (const float*)b, idx, (float*)dst, n, channels);

@@ -7,8 +7,9 @@ import numpy as np
 import torch
 
 
-def room_grid(n_side, seed=0):
-    h = max(2, n_side * 72 // 256)
+def room_grid(n_side, seed=0, walls=True):
+    """walls=False: the floor alone -- "room-4096" of BASELINE config 1 is room_grid(64, walls=False): 64 x 64 = 4,096 voxels."""
+    h = max(2, n_side * 72 // 256) if walls else 0
     xs, ys = np.meshgrid(np.arange(n_side), np.arange(n_side), indexing="ij")
     floor = np.stack([xs.ravel(), ys.ravel(), np.zeros(n_side * n_side, int)], 1)
     yy, zz = np.meshgrid(np.arange(n_side), np.arange(1, h + 1), indexing="ij")
@@ -19,13 +20,13 @@ def room_grid(n_side, seed=0):
     return gc[perm]
 
 
-def room_chunk(n_side=256, seed=0, lang_dim=768, num_classes=20, batch=1):
+def room_chunk(n_side=256, seed=0, lang_dim=768, num_classes=20, batch=1, walls=True):
     """Input dict (CPU tensors) of `batch` chunks: coord, grid_coord, feat (11 = color3, opacity1,
     quat4, scale3), lang_feat (unit rows), valid_feat_mask (90 %), segment (-1 = ignore), offset."""
     parts = []
     for b in range(batch):
         g = torch.Generator().manual_seed(seed + b)
-        gc = torch.from_numpy(room_grid(n_side, seed + b))
+        gc = torch.from_numpy(room_grid(n_side, seed + b, walls))
         n = len(gc)
         coord = gc.float() * 0.02 + torch.rand(n, 3, generator=g) * 0.02
         color = torch.rand(n, 3, generator=g) * 2 - 1

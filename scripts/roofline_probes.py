@@ -9,8 +9,11 @@ Two uses:
 
 Algorithmic work per launch (DESIGN.md section 4 / SURVEY 8d):
   conv_fwd / conv_wgrad  dec0 submanifold conv, n = 102,400 sites, C = 768: 2 * pairs * C^2 FLOP; bytes 2 n C 2 + 27 C^2 2
-  attn_fwd / attn_bwd    dec0 window attention: 100 windows x 16 heads, K = 1024, d = 48: 4 K^2 d per (window, head) FLOP
-                         forward, 2.5 x backward (5 products, recompute not counted); bytes: qkv read + out written (fwd)
+  attn_fwd / attn_bwd    dec0 window attention (head-major kernels, csrc/attention_hm.hip): 100 windows x 16 heads, K = 1024,
+                         d = 48: 4 K^2 d per (window, head) FLOP forward, 2.5 x backward (5 products, recompute not counted);
+                         bytes: q, k, v read + out written (fwd); + dO, O read, dO copy, dq, dk, dv written (bwd)
+  unpool_fwd / unpool_bwd  the gather / scatter launches of the step at the dec0 unpooling seam (grid-pool scatter of the north
+                         star): n (3 * 1536 + 4) bytes forward, n 1540 + n/4 1540 bytes backward
   gather_hbm             row gather of 819,200 x 768 bf16 rows (the config-3 batch: 2.5 GB working set, far beyond the
                          256 MiB Infinity Cache): n (2 * 1536 + 4) bytes
   scan                   config 5: 1,000,000 x 768 bf16 unit rows x 160 text rows -> sigmoid -> max/argmax: n (1536 + 8) bytes
@@ -57,20 +60,35 @@ def build(n_side=256, which=None):
             probes.append(dict(name="conv_wgrad", kernel="k_wgrad8", run=lambda: nv.subm_conv_wgrad(x, go, nbr, perm, blocks), bound="mfma",
                                flops=fl, bytes=2 * lv.n * C * 2 + 27 * C * C * 4, note="k_wgrad8<true> subm conv wgrad (dec0: %s)" % note))
     if want("attn_fwd") or want("attn_bwd"):
+        # the kernels the step runs since round 3: head-major, window-ordered q / k / v (csrc/attention_hm.hip)
         win = lv.window(0, K)
         qkv = torch.randn(lv.n, 3 * C, device="cuda", generator=g).to(torch.bfloat16)
         dout = torch.randn(lv.n, C, device="cuda", generator=g).to(torch.bfloat16)
         sc = d ** -0.5
-        out, lse = nv.window_attn_fwd(qkv, win, H, sc, nv.ATTN_MFMA)
+        hm = nv.headmajor_pack(qkv, win, H, 3, sc * nv.LOG2E)
+        out, nlse2 = nv.window_attn_hm_fwd(hm, win, H)
         fl = win.num_windows * H * 4.0 * K * K * d
         note = "%d windows x %d heads, K=%d, d=%d" % (win.num_windows, H, K, d)
         if want("attn_fwd"):
-            probes.append(dict(name="attn_fwd", kernel="k_attn_fwd", run=lambda: nv.window_attn_fwd(qkv, win, H, sc, nv.ATTN_MFMA), bound="mfma",
-                               flops=fl, bytes=lv.n * C * 2 * 4, note="window attention forward (dec0: %s)" % note))
+            probes.append(dict(name="attn_fwd", kernel="k_attn_hm_fwd", run=lambda: nv.window_attn_hm_fwd(hm, win, H), bound="mfma",
+                               flops=fl, bytes=lv.n * C * 2 * 4, note="head-major window attention forward k_attn_hm_fwd<48> (dec0: %s)" % note))
         if want("attn_bwd"):
-            probes.append(dict(name="attn_bwd", kernel="k_attn_bwd", run=lambda: nv.window_attn_bwd(qkv, out, dout, lse, win, H, sc, nv.ATTN_MFMA),
+            probes.append(dict(name="attn_bwd", kernel="k_attn_hm_d", run=lambda: nv.window_attn_hm_bwd(hm, out, dout, nlse2, win, H, sc),
                                bound="mfma", flops=2.5 * fl, bytes=lv.n * C * 2 * 8,
-                               note="window attention backward, dQ + dK/dV kernels (dec0: %s)" % note))
+                               note="head-major window attention backward, k_attn_hm_dq<48> + k_attn_hm_dkv<48> (dec0: %s)" % note))
+    if want("unpool_fwd") or want("unpool_bwd"):
+        # the gather / scatter launches the STEP runs at the dec0 unpooling seam (ptv3:471-482): parent + child[cluster] forward
+        # (k_gather_add_v), segment sum of the gradient back to the 25,600 coarse sites backward (k_segment_reduce_v)
+        l1 = plan.levels[1]
+        skip = torch.randn(lv.n, C, device="cuda", generator=g).to(torch.bfloat16)
+        up = torch.randn(l1.n, C, device="cuda", generator=g).to(torch.bfloat16)
+        if want("unpool_fwd"):
+            probes.append(dict(name="unpool_fwd", kernel="k_gather_add", run=lambda: nv.gather_add_rows(skip, up, l1.cluster), bound="hbm",
+                               bytes=lv.n * (3 * C * 2 + 4), note="dec0 unpool forward: skip + up[cluster], %d x %d bf16 (the step's own launch)" % (lv.n, C)))
+        if want("unpool_bwd"):
+            probes.append(dict(name="unpool_bwd", kernel="k_segment_reduce", run=lambda: nv.segment_reduce(skip, l1.indices, l1.idx_ptr, l1.n, False),
+                               bound="hbm", bytes=lv.n * (C * 2 + 4) + l1.n * (C * 2 + 4),
+                               note="dec0 unpool backward: segment sum %d -> %d x %d bf16 (the step's own launch)" % (lv.n, l1.n, C)))
     if want("gather_hbm"):
         nb = 8 * lv.n
         src = torch.randn(nb, C, device="cuda", generator=g).to(torch.bfloat16)

@@ -198,3 +198,49 @@ def test_uniform_102400_stress_forward_backward():
         assert n_par > 300
     finally:
         RUNTIME.update(old)
+
+
+def test_config5_million_gaussian_region_chunked_inference_end_to_end():
+    """BASELINE config 5 END TO END on one GPU (round 3): a 1,000,000-Gaussian region (room(800): 640,000 floor + 2 x 180,000
+    wall voxels, depth 10) -> LangPretrainer.eval()(input, chunk_size=600000), the call form of the reference's evaluator and
+    tester (engines/hooks/evaluator.py:762, engines/test.py:329-351, models/default.py:115-176: chunks of 600,000 and 400,000
+    Gaussians, each through the full 91.7 M-parameter encoder) -> the open-vocabulary feature x text scan with a 160-label text
+    table (matterport-nyu160; test.py:377-378, evaluator.py:793-800).
+    Checked: finite unit rows; both chunks equal their stand-alone forwards bit for bit (so nothing in the 600,000-row chunk --
+    600,000 x 3,072 MLP activations = 1.84 G elements, past 32-bit element counts; 16.2 M rulebook entries; 586 windows at
+    dec0 -- depends on the rows around it); the scan against the reference math on a row range; peak memory inside 288 GB."""
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.pointcept_api import MODELS, RUNTIME, bench_runtime
+    from scenesplat_amd.synthetic import LANG_PTV3, room_chunk
+    torch.cuda.reset_peak_memory_stats()
+    d = {k: v.cuda() for k, v in room_chunk(n_side=800, seed=2, lang_dim=0).items()}
+    n = d["coord"].shape[0]
+    assert n == 1_000_000 and (600_000 * 3072) > 2 ** 31
+    model = MODELS.build(dict(type="LangPretrainer", backbone=dict(type="PT-v3m1", **LANG_PTV3), criteria=[])).cuda().eval()
+    old = dict(RUNTIME)
+    RUNTIME.update(bench_runtime())
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            torch.manual_seed(5)
+            feat = model(dict(d), chunk_size=600000)["point_feat"]["feat"]
+            torch.manual_seed(5)
+            # the draws of chunk 1 (SerializedPooling's curve shuffles) come first in the chunked call: replay them, then chunk 2
+            sub1 = {k: v[:600000] for k, v in d.items() if k != "offset"}
+            sub1["offset"] = torch.tensor([600000], device="cuda")
+            f1 = model(sub1)["point_feat"]["feat"]
+            sub2 = {k: v[600000:] for k, v in d.items() if k != "offset"}
+            sub2["offset"] = torch.tensor([400000], device="cuda")
+            f2 = model(sub2)["point_feat"]["feat"]
+    finally:
+        RUNTIME.clear(); RUNTIME.update(old)
+    assert feat.shape == (n, 768) and torch.isfinite(feat).all()
+    assert torch.allclose(feat.float().norm(dim=1), torch.ones(n, device="cuda"), atol=2e-3)
+    assert torch.equal(feat[:600000], f1) and torch.equal(feat[600000:], f2)
+    text = torch.nn.functional.normalize(torch.randn(160, 768, device="cuda", generator=torch.Generator("cuda").manual_seed(1)), dim=1).to(torch.bfloat16)
+    mp, am = nv.feat_text_scan(feat.to(torch.bfloat16).contiguous(), text)
+    sub = slice(777_000, 779_000)
+    ref = torch.sigmoid(feat[sub].to(torch.bfloat16).float() @ text.float().t()).max(1)
+    assert torch.allclose(mp[sub], ref.values, atol=3e-4) and (am[sub].long() == ref.indices).float().mean() > 0.99
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    print("config 5: 1,000,000 Gaussians in chunks of 600,000 / 400,000 -> (n, 768) unit features -> 160-label scan; peak memory %.1f GiB" % peak)
+    assert peak < 268

@@ -219,3 +219,41 @@ def test_trainer_runs_lang_pretrainer_on_gpu(tmp_path):
     assert hist[-1]["loss"] < hist[0]["loss"]                 # it learns something on repeated data
     ck = torch.load(os.path.join(str(tmp_path), "model", "model_last.pth"), weights_only=True)
     assert ck["epoch"] == 2 and any(k.startswith("backbone.dec.dec0.block0.cpe.0.weight") for k in ck["state_dict"])
+
+
+def test_config1_room4096_ptv3_small_k256_through_the_trainer(tmp_path):
+    """BASELINE config 1 at its STATED workload: "room-4096" (64 x 64 floor = 4,096 Gaussians, 11 = 14 - 3
+    attribute channels as features), PTv3-small = the lang-pretrain topology with enc_patch_size = dec_patch_size = 256,
+    lang-feat regression (768-d targets, the 3 criteria) through the pointcept engine: DefaultTrainer + hooks, 2 epochs x 2
+    steps, AdamW groups, OneCycleLR, checkpoint.  (The reference runs this on CPU as plumbing; the product path has no CPU
+    fallback, so the same run drives the HIP kernels: 16 windows of 256 at every full-resolution block.)"""
+    from scenesplat_amd.pointcept_api import engine, RUNTIME, bench_runtime
+    from scenesplat_amd.synthetic import LANG_PTV3, room_chunk
+    small = dict(LANG_PTV3, enc_patch_size=(256,) * 4, dec_patch_size=(256,) * 3)
+    model_cfg = dict(type="LangPretrainer", backbone=dict(type="PT-v3m1", **small),
+                     criteria=[dict(type="CosineSimilarity", reduction="mean", loss_weight=1.0),
+                               dict(type="L2Loss", reduction="mean", loss_weight=1.0),
+                               dict(type="AggregatedContrastiveLoss", temperature=0.2, reduction="mean", loss_weight=0.02, schedule="last_75")])
+    cfg = dict(model=model_cfg, device="cuda", eval_epoch=2, save_path=str(tmp_path), enable_amp=True, clip_grad=1.0,
+               optimizer=dict(type="AdamW", lr=1e-3, weight_decay=0.05), param_dicts=[dict(keyword="block", lr=1e-4)],
+               scheduler=dict(type="OneCycleLR", max_lr=[1e-3, 1e-4], pct_start=0.05, anneal_strategy="cos", div_factor=10.0,
+                              final_div_factor=1000.0),
+               hooks=[dict(type="IterationTimer"), dict(type="InformationWriter", interval=1), dict(type="CheckpointSaver")])
+    loader = [room_chunk(n_side=64, seed=i, lang_dim=768, num_classes=20, batch=1, walls=False) for i in range(2)]
+    assert all(d["feat"].shape == (4096, 11) and d["lang_feat"].shape == (4096, 768) for d in loader)
+    old = dict(RUNTIME)
+    try:
+        RUNTIME.update(bench_runtime())
+        tr = engine.Trainer(cfg, train_loader=loader)
+        tr.train()
+    finally:
+        RUNTIME.clear(); RUNTIME.update(old)
+    hist = [h for h in tr.hooks if isinstance(h, engine.InformationWriter)][0].history
+    assert len(hist) == 4 and all(np.isfinite(h["loss"]) for h in hist)
+    assert hist[-1]["loss"] < hist[0]["loss"]
+    ck = torch.load(os.path.join(str(tmp_path), "model", "model_last.pth"), weights_only=True)
+    assert ck["epoch"] == 2 and len(ck["state_dict"]) >= 393
+    # the plan of the workload is what config 1 states: 4,096 -> 1,024 -> 256 -> 64 sites, 16 windows of 256 at level 0
+    plan = tr.model.backbone.prepare_plan({k: v.cuda() for k, v in loader[0].items() if torch.is_tensor(v)})
+    assert [lv.n for lv in plan.levels] == [4096, 1024, 256, 64]
+    assert plan.levels[0].window(0, 256).num_windows == 16
