@@ -253,6 +253,65 @@ def secondary_lines(log, steps=3):
                                                            dtype="bf16 autocast + bf16x3 conv")
         del model, data
         gc.collect(); torch.cuda.empty_cache()
+        # ---- variable-size training (round 3): what real batches look like.  The reference crops every sample to at most 192,000
+        # Gaussians (SphereCrop, configs/concat_dataset/lang-pretrain-...-contrastive.py:271) and runs 2 chunks per GPU
+        # (submit/...-nccl.sh:47-51), so no two steps share a plan shape: every step runs EAGERLY (no hipGraph replay), with a new
+        # plan.  N per chunk drawn per step from 60,000 .. 192,000 (seeded); B = 2.
+        RUNTIME.update(bench_runtime())
+        torch.manual_seed(1)
+        model = MODELS.build(dict(type="PT-v3m1", **LANG_PTV3)).cuda().train()
+        import random as _random
+        rng = _random.Random(5)
+        big = room_chunk(352, 3, lang_dim=0)                     # 352^2 + 2 * 352 * 99 = 193,600 unique voxels to crop from
+        gcb, fb = big["grid_coord"], big["feat"]
+
+        def batch_of(sizes):
+            parts, off = [], []
+            for j, m in enumerate(sizes):
+                sel = torch.randperm(len(gcb), generator=torch.Generator().manual_seed(100 * j + m))[:m]
+                parts.append((gcb[sel], fb[sel])); off.append(m)
+            return dict(grid_coord=torch.cat([p[0] for p in parts]).cuda(), feat=torch.cat([p[1] for p in parts]).cuda(),
+                        offset=torch.tensor(off).cumsum(0).cuda())
+        sizes = [[rng.randrange(60000, 192001) for _ in range(2)] for _ in range(steps + 2)]
+        batches = [batch_of(sz) for sz in sizes]
+        tot = 0
+        for i, b in enumerate(batches):
+            if i == 2:
+                torch.cuda.synchronize(); t0 = time.perf_counter(); tot = 0
+            model.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                o = model(dict(b))
+            torch.autograd.backward(o.feat, grad_tensors=torch.ones_like(o.feat))
+            tot += b["feat"].shape[0]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["variable_size_training_b2"] = dict(metric="Gaussians/s encoder fwd+bwd, EAGER launches, 2 chunks per step of 60,000-192,000 Gaussians each (a new plan shape every step), 1 GPU",
+                                                value=tot / dt, unit="Gaussians/s", ms_per_step=dt / steps * 1e3, steps=steps,
+                                                gaussians_per_step=tot / steps, dtype="bf16")
+        del model, batches
+        gc.collect(); torch.cuda.empty_cache()
+        # ---- BASELINE config 5 end to end: 1,000,000-Gaussian region -> LangPretrainer.eval()(input, chunk_size=600000) (the call
+        # form of engines/test.py:329-351 / evaluator.py:762) -> 160-label feature x text scan
+        from scenesplat_amd import native as nv5
+        torch.manual_seed(1)
+        model = MODELS.build(dict(type="LangPretrainer", backbone=dict(type="PT-v3m1", **LANG_PTV3), criteria=[])).cuda().eval()
+        data = {k: v.cuda() for k, v in room_chunk(800, 2, lang_dim=0).items()}
+        text = torch.nn.functional.normalize(torch.randn(160, 768, device="cuda"), dim=1).to(torch.bfloat16)
+        torch.cuda.reset_peak_memory_stats()
+        times = []
+        for i in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                feat = model(dict(data), chunk_size=600000)["point_feat"]["feat"]
+            mp_, am_ = nv5.feat_text_scan(feat.to(torch.bfloat16).contiguous(), text)
+            torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+            del feat
+        n5 = data["feat"].shape[0]
+        out["config5_open_vocab_inference_1m"] = dict(metric="Gaussians/s open-vocabulary inference end to end: 1,000,000-Gaussian region, chunk_size=600000 encoder forward (2 chunks) + 160-label scan, 1 GPU",
+                                                      value=n5 / min(times[1:]), unit="Gaussians/s", ms_per_region=min(times[1:]) * 1e3,
+                                                      peak_mem_GiB=torch.cuda.max_memory_allocated() / 2**30, dtype="bf16")
+        del model, data
+        gc.collect(); torch.cuda.empty_cache()
     except Exception as e:   # noqa: BLE001  (secondary lines must never take the headline down)
         log("secondary: %s: %s" % (type(e).__name__, e))
         out["error"] = "%s: %s" % (type(e).__name__, e)

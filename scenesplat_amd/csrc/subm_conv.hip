@@ -147,6 +147,11 @@ k_subm_gemm(const unsigned short* __restrict__ in, const unsigned short* __restr
   };
   const int taps_per_z = (taps + gridDim.z - 1) / gridDim.z;
   const int tap_beg = blockIdx.z * taps_per_z, tap_end = min(taps, tap_beg + taps_per_z);
+  // a split-K slice can be EMPTY (27 taps over 8 slices of 4: slice 7 starts at tap 28).  Its workgroups used to fall through to
+  // the epilogue without ever passing a barrier, read rowid_s before the threads that fill it had written it, and added zeros at
+  // row = whatever LDS held: an out-of-bounds atomic (memory access fault at n = 4,096, round 3).  Nothing to add: leave.
+  if (tap_beg >= tap_end) return;
+  __syncthreads();                       // rowid_s is complete for every path below
   for (int tg = tap_beg; tg < tap_end; tg += CV_TG) {
     const int nt = min(CV_TG, tap_end - tg);
     __syncthreads();                     // previous group's LDS reads are done

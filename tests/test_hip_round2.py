@@ -544,19 +544,21 @@ def test_steady_state_error_inside_a_capture_falls_back_to_eager_with_fresh_weig
                 raise RuntimeError("injected failure inside the capture")
             return r
         steady = SteadyStateStep(failing, model.parameters(), warmup=0)
-        steady(model.prepare_plan(d), dict(feat=d["feat"], cot=cot))          # the sync-checked eager step
+        perms = model.draw_perms()                                             # one curve permutation for every call below
+        steady(model.prepare_plan(d, perms=perms), dict(feat=d["feat"], cot=cot))          # the sync-checked eager step
         with torch.no_grad():                                                  # "optimizer step" before the capture is attempted
             for p in model.parameters():
                 p.mul_(1.05)
-        out = steady(model.prepare_plan(d), dict(feat=d["feat"], cot=cot))["feat"].float()
+        out = steady(model.prepare_plan(d, perms=perms), dict(feat=d["feat"], cot=cot))["feat"].float()
         assert steady.refused is not None and "injected" in steady.refused and steady.poisoned is None and steady.replays == 0
         assert nv.stream_capture_status() == 0
         # the fallback equals a plain eager step on the current weights
         for p in model.parameters():
             p.grad = None
-        ref = fn(model.prepare_plan(d), dict(feat=d["feat"], cot=cot))["feat"].detach().float()
-        assert float((out - ref).norm() / ref.norm()) < 1e-3
-        out2 = steady(model.prepare_plan(d), dict(feat=d["feat"], cot=cot))["feat"].float()      # refused signature: eager from now on
+        ref = fn(model.prepare_plan(d, perms=perms), dict(feat=d["feat"], cot=cot))["feat"].detach().float()
+        # two eager runs of this bf16 step differ by ~3e-3 (fp32 atomics); weights one step stale are O(0.1)
+        assert float((out - ref).norm() / ref.norm()) < 1e-2
+        out2 = steady(model.prepare_plan(d, perms=perms), dict(feat=d["feat"], cot=cot))["feat"].float()      # refused signature: eager from now on
         assert steady.replays == 0 and torch.isfinite(out2).all()
 
 
