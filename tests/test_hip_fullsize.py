@@ -207,7 +207,7 @@ def test_config5_million_gaussian_region_chunked_inference_end_to_end():
     Gaussians, each through the full 91.7 M-parameter encoder) -> the open-vocabulary feature x text scan with a 160-label text
     table (matterport-nyu160; test.py:377-378, evaluator.py:793-800).
     Checked: finite unit rows; both chunks equal their stand-alone forwards bit for bit (so nothing in the 600,000-row chunk --
-    600,000 x 3,072 MLP activations = 1.84 G elements, past 32-bit element counts; 16.2 M rulebook entries; 586 windows at
+    600,000 x 3,072 bf16 MLP activations = 3.7 GB, byte offsets past 2^31; 16.2 M rulebook entries; 586 windows at
     dec0 -- depends on the rows around it); the scan against the reference math on a row range; peak memory inside 288 GB."""
     from scenesplat_amd import native as nv
     from scenesplat_amd.pointcept_api import MODELS, RUNTIME, bench_runtime
@@ -215,7 +215,7 @@ def test_config5_million_gaussian_region_chunked_inference_end_to_end():
     torch.cuda.reset_peak_memory_stats()
     d = {k: v.cuda() for k, v in room_chunk(n_side=800, seed=2, lang_dim=0).items()}
     n = d["coord"].shape[0]
-    assert n == 1_000_000 and (600_000 * 3072) > 2 ** 31
+    assert n == 1_000_000 and (600_000 * 3072 * 2) > 2 ** 31          # bf16 MLP activations: byte offsets past 2^31
     model = MODELS.build(dict(type="LangPretrainer", backbone=dict(type="PT-v3m1", **LANG_PTV3), criteria=[])).cuda().eval()
     old = dict(RUNTIME)
     RUNTIME.update(bench_runtime())
