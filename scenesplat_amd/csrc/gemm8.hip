@@ -264,6 +264,21 @@ k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__
   }
 
   // ---- epilogue: acc[ha][mi][hb][ni][r] = C[site 128wr + 64ha + 16mi + lq][channel 64wc + 32hb + 16ni + 4g + r] ----
+  // HM: the (section, head, d) split of a lane's four column groups is fixed for the whole tile: computed once (the divisions
+  // by the runtime head width cost ~40 instructions each)
+  int64_t hm_base[2][2];
+  float hm_mul[2][2];
+  if (HM) {
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col = min(n0 + 64 * wc + 32 * hb + 16 * ni + 4 * g, N - 4);
+        const int sec = col / hm_c, cc = col - sec * hm_c, hd = cc / hm_d, dd = cc - hd * hm_d;
+        hm_base[hb][ni] = ((int64_t)sec * (hm_c / hm_d) + hd) * M * hm_d + dd;
+        hm_mul[hb][ni] = sec == 0 ? hm_scale : 1.f;
+      }
+  }
 #pragma unroll
   for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
@@ -282,9 +297,9 @@ k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__
           if (bias) { float4 bv = *reinterpret_cast<const float4*>(bias + col); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
           OutT* op = out + row * N + col;
           if (HM) {       // (section, head, slot, d): 4 consecutive channels never straddle a head (hm_d % 4 == 0)
-            const int sec = col / hm_c, cc = col - sec * hm_c, hd = cc / hm_d, dd = cc - hd * hm_d;
-            if (sec == 0) { v[0] *= hm_scale; v[1] *= hm_scale; v[2] *= hm_scale; v[3] *= hm_scale; }
-            op = out + (((int64_t)sec * (hm_c / hm_d) + hd) * M + row) * hm_d + dd;
+            const float m_ = hm_mul[hb][ni];
+            v[0] *= m_; v[1] *= m_; v[2] *= m_; v[3] *= m_;
+            op = out + hm_base[hb][ni] + row * hm_d;
           }
           if (sizeof(OutT) == 2) {
             uint2 u; u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
