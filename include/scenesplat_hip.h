@@ -82,6 +82,12 @@ int ss_window_attn_bwd(const void* qkv, const void* out, const void* dout, const
                        int64_t n_pad, int channels, int num_heads, float scale, int dtype, int impl, void* dqkv,
                        void* workspace, size_t workspace_bytes, ss_stream_t stream);
 
+/* ---- grouped fp32 -> bf16 cast of many tensors in one launch (the bf16 weight shadows; replaces one torch copy kernel per tensor).
+ * desc: 3 int64 per tensor {src f32 pointer, dst bf16 pointer, numel}; wg_start (nprob + 1): first workgroup of each tensor at
+ * 8192 elements per workgroup (ss_cast_bf16_group_elems_per_workgroup) */
+int ss_cast_bf16_group(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups, ss_stream_t stream);
+int ss_cast_bf16_group_elems_per_workgroup(void);
+
 /* ---- runtime queries -------------------------------------------------------------------- */
 /* 0 = the stream is not capturing, 1 = capturing, 2 = its capture was invalidated (abandon it: never end it), < 0 = query failed */
 int ss_stream_capture_status(ss_stream_t stream);

@@ -414,6 +414,43 @@ extern "C" int ss_transpose16_group(const int64_t* desc, const int32_t* wg_start
   return SS_OK;
 }
 
+// ---- grouped fp32 -> bf16 cast: the bf16 shadows of ALL GEMM / conv weights of a model in ONE launch (round 3) ----------------
+// torch._foreach_copy_ with a dtype change falls back to one copy kernel per tensor: 206 launches and 1.2 ms per step for the
+// lang-pretrain model (profiles/r03_kernel_stats.md, first take).  desc: 3 int64 words per tensor = {src f32, dst bf16, numel};
+// wg_start (nprob + 1); a workgroup owns 8,192 consecutive elements of one tensor (tensor bases are allocator-aligned).
+#define CASTG_PER_WG 8192
+__global__ void __launch_bounds__(256)
+k_cast_bf16_group(const int64_t* __restrict__ desc, const int32_t* __restrict__ wg_start, int nprob) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = nprob - 1;                       // last problem whose first workgroup is <= b
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (wg_start[mid] <= b) lo = mid; else hi = mid - 1; }
+  const int64_t* d = desc + (int64_t)lo * 3;
+  const float* src = reinterpret_cast<const float*>(d[0]);
+  unsigned short* dst = reinterpret_cast<unsigned short*>(d[1]);
+  const int64_t numel = d[2];
+  const int64_t e0 = (int64_t)(b - wg_start[lo]) * CASTG_PER_WG;
+#pragma unroll
+  for (int i = 0; i < CASTG_PER_WG / (256 * 8); ++i) {
+    const int64_t e = e0 + ((int64_t)i * 256 + threadIdx.x) * 8;
+    if (e + 8 <= numel) {
+      const float4 a = *reinterpret_cast<const float4*>(src + e), c = *reinterpret_cast<const float4*>(src + e + 4);
+      uint4 o;
+      o.x = pack_bf16x2(a.x, a.y); o.y = pack_bf16x2(a.z, a.w); o.z = pack_bf16x2(c.x, c.y); o.w = pack_bf16x2(c.z, c.w);
+      *reinterpret_cast<uint4*>(dst + e) = o;
+    } else {
+      for (int64_t k = e; k < numel; ++k) dst[k] = f32_to_bf16(src[k]);
+    }
+  }
+}
+
+extern "C" int ss_cast_bf16_group_elems_per_workgroup(void) { return CASTG_PER_WG; }
+extern "C" int ss_cast_bf16_group(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups, hipStream_t stream) {
+  if (nprob <= 0 || total_workgroups <= 0) return SS_OK;
+  if (!desc || !wg_start) return SS_ERR_ARG;
+  SS_LAUNCH(k_cast_bf16_group, dim3((unsigned)total_workgroups), dim3(256), 0, stream, desc, wg_start, nprob);
+  return SS_OK;
+}
+
 // ---- grouped form of k_subm_weight_mirror: the dgrad weights of ALL convs of a model in one launch (refreshed with the bf16 shadows) ----
 // desc: 5 int64 words per problem = {w, wt, cout, taps, cin}; wg_start (nprob + 1); a workgroup owns one (tap, 32 x 32) tile.
 __global__ void __launch_bounds__(256)

@@ -851,3 +851,21 @@ def stream_capture_status(stream=None):
     """0 = not capturing, 1 = capturing, 2 = the capture was invalidated (it must be abandoned, never ended), -1 = unknown."""
     st = stream if stream is not None else torch.cuda.current_stream()
     return int(lib().ss_stream_capture_status(ctypes.c_void_p(st.cuda_stream)))
+
+
+def cast_bf16_group(srcs, dsts):
+    """ONE launch: dst (bf16) = src (fp32) for every pair of equally shaped contiguous tensors (the weight shadows)."""
+    import numpy as np
+    if not srcs:
+        return
+    dev = srcs[0].device
+    per = lib().ss_cast_bf16_group_elems_per_workgroup()
+    desc = np.zeros((len(srcs), 3), dtype=np.int64)
+    starts = [0]
+    for j, (s, d) in enumerate(zip(srcs, dsts)):
+        if s.dtype != torch.float32 or d.dtype != torch.bfloat16 or s.numel() != d.numel() or not (s.is_contiguous() and d.is_contiguous()):
+            raise RuntimeError("cast_bf16_group: contiguous fp32 -> bf16 pairs of equal size")
+        desc[j] = (s.data_ptr(), d.data_ptr(), s.numel())
+        starts.append(starts[-1] + (s.numel() + per - 1) // per)
+    d_dev, s_dev = _upload_descriptors(desc, starts, dev)
+    check(lib().ss_cast_bf16_group(_p(d_dev), _p(s_dev), len(srcs), starts[-1], _stream()), "ss_cast_bf16_group")

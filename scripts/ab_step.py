@@ -11,7 +11,8 @@ from scenesplat_amd.synthetic import LANG_PTV3, room_chunk
 which = sys.argv[1] if len(sys.argv) > 1 else "defer"
 blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-RUNTIME["attn_impl"] = nv.ATTN_MFMA; RUNTIME["conv_dtype"] = torch.bfloat16
+from scenesplat_amd.pointcept_api import bench_runtime
+RUNTIME.update(bench_runtime())
 model = MODELS.build(dict(type="PT-v3m1", **LANG_PTV3)).cuda().train()
 data = {k: v.cuda() for k, v in room_chunk(256, 0, lang_dim=0).items()}
 cot = torch.randn(len(data["feat"]), 768, device="cuda").to(torch.bfloat16)
@@ -47,6 +48,10 @@ def setter(on):
         RUNTIME["fuse_ln_seam"] = on
     elif which == "rb_hash":
         nv.RULEBOOK_HASHED = on
+    elif which == "attn_hm":
+        RUNTIME["attn_headmajor"] = on
+    elif which == "group_cast":
+        SF.SHADOW_GROUP_CAST = on
     elif which == "mask_small":
         import scenesplat_amd.plan as P
         P.CONV_MASK_MIN_SITES = 4096 if on else 16384
@@ -54,7 +59,13 @@ def setter(on):
         raise SystemExit("unknown switch")
 
 
+_params = [p for p in model.parameters()]
+
+
 def step():
+    if which == "group_cast":
+        with torch.no_grad():
+            torch._foreach_add_(_params, 0.0)          # an "optimizer step": every shadow is re-cast by the next forward
     model.zero_grad(set_to_none=True)
     plan, state["plan"] = state["plan"], None
     with torch.autocast("cuda", dtype=torch.bfloat16):
