@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the N>1 path on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--exchange", default="stage", choices=["stage", "ddp"],
+                    help="N > 1 gradient averaging: one all-reduce per model stage (scenesplat_amd/grad_exchange.py) or torch DDP buckets")
     ap.add_argument("--cpu-n-side", type=int, default=256, help="room side of the CPU-baseline chunk (256 -> the metric's 102,400 Gaussians, about a minute on 16 cores)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay forward+backward as a hipGraph once the plan shape repeats (auto: single-rank runs)")
@@ -335,7 +337,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     # SS_BENCH_FORCE_DDP=1 (DIAGNOSTIC, single rank): a one-rank RCCL process group and the DDP wrapper of the N > 1 path -- bucket hooks,
     # bucket views and a (trivial) all-reduce per bucket run as they do with more ranks; the line it prints is not the metric
-    force_ddp = world == 1 and os.environ.get("SS_BENCH_FORCE_DDP") == "1"
+    force_ddp = world == 1 and os.environ.get("SS_BENCH_FORCE_DDP") in ("1", "stage", "ddp")
+    if force_ddp and os.environ.get("SS_BENCH_FORCE_DDP") in ("stage", "ddp"):
+        args.exchange = os.environ["SS_BENCH_FORCE_DDP"]
+    elif force_ddp:
+        args.exchange = "ddp"
     if force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -359,10 +365,19 @@ def main():
     torch.manual_seed(1234 + rank)
     model = MODELS.build(dict(type="PT-v3m1", **LANG_PTV3)).to(dev).train()
     net = model
-    if world > 1 or force_ddp:
+    exchange = None
+    if (world > 1 or force_ddp) and args.exchange == "ddp":
         # DDP as the reference builds it (engines/defaults.py:13-34): broadcast_buffers=False
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
                                                         gradient_as_bucket_view=True, bucket_cap_mb=100)
+    elif world > 1 or force_ddp:
+        # round 3 (default): the same gradient average as one all-reduce per model STAGE, issued when the stage's gradients become
+        # final in the backward pass (dec0 first: 52 % of the bytes, overlapped with the rest of the backward); no wrapper, no
+        # per-parameter bucket copies (DDP: +2.3 ms of copies per step on one rank, round 2)
+        from scenesplat_amd.grad_exchange import StageGradExchange
+        for t_ in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t_.data, src=0)
+        exchange = StageGradExchange(model, force=force_ddp)
     if args.fixture == "uniform":
         from scenesplat_amd.synthetic import uniform_chunk
         data = {k: v.to(dev) for k, v in uniform_chunk(seed=rank).items()}
@@ -384,6 +399,8 @@ def main():
             out = net(dict(feat=t["feat"], grid_coord=data["grid_coord"], offset=data["offset"], plan=plan))
         # backward from the seeded random cotangent, fed directly as the output gradient (no loss kernels)
         torch.autograd.backward(out.feat, grad_tensors=t["cot"])
+        if exchange is not None:
+            exchange.finish()
         return {"feat": out.feat}
 
     # Steady state (scenesplat_amd/steady_state.py): every chunk of the room has the same plan SHAPE, so after two eager
@@ -464,7 +481,7 @@ def main():
                                     + " PT-v3m1 lang-pretrain encoder (91.71M params, in=11, out=768) fwd+bwd, "
                                     "1 chunk of %d Gaussians per GPU per step, serialization included") % (n, n),
                        "gaussians_per_chunk": n, "chunks_per_gpu": 1,
-                       "parallelism": "dp%d" % world, "attention_kernel": "mfma" if impl == nv.ATTN_MFMA else "simt",
+                       "parallelism": "dp%d" % world, "gradient_exchange": (args.exchange if (world > 1 or force_ddp) else "none"), "attention_kernel": "mfma" if impl == nv.ATTN_MFMA else "simt",
                        "execution": ("hipGraph replay of forward+backward (%d of the %d timed steps; plan rebuilt and copied in every step)"
                                      % (steady.replays - replays_before, args.steps)) if steady.replays > replays_before else "eager launches"},
         }

@@ -313,6 +313,7 @@ class Trainer(TrainerBase):
         self.best_metric_value = -float("inf")
         self.logger = logger
         self.device = torch.device(cfg.get("device", "cuda"))
+        self.grad_exchange = None
         self.model = self.build_model()
         self.train_loader, self.val_loader = train_loader, None
         self.optimizer = build_optimizer(cfg["optimizer"], self.model, cfg.get("param_dicts"))
@@ -328,7 +329,17 @@ class Trainer(TrainerBase):
         model = MODELS.build(self.cfg["model"])
         if self.cfg.get("sync_bn"):
             model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
-        return create_ddp_model(model.to(self.device), broadcast_buffers=False,
+        model = model.to(self.device)
+        if self.cfg.get("grad_exchange") == "stage" and get_world_size() > 1:
+            # round 3: the gradient average of DDP (engines/defaults.py:13-34) as one all-reduce per model STAGE, launched when the
+            # stage's gradients become final in the backward pass (scenesplat_amd/grad_exchange.py); no wrapper, no bucket copies.
+            # Same initial weights on every rank, as DDP's constructor broadcast enforces:
+            from ..grad_exchange import StageGradExchange
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, src=0)
+            self.grad_exchange = StageGradExchange(model)
+            return model
+        return create_ddp_model(model, broadcast_buffers=False,
                                 find_unused_parameters=self.cfg.get("find_unused_parameters", False))
 
     def train(self):
@@ -408,6 +419,8 @@ class Trainer(TrainerBase):
             loss = out["loss"]
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        if self.grad_exchange is not None:
+            self.grad_exchange.finish()
         if self.cfg.get("clip_grad") is not None:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.cfg["clip_grad"])
         self.optimizer.step()

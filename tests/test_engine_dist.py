@@ -152,3 +152,116 @@ def test_steady_state_step_disabled_is_the_plain_callable():
     assert calls == ["plan-a"] and step.eager_steps == 1 and step.replays == 0
     assert out["y"].grad_fn is None and float(out["y"]) == 3.0
     assert torch.equal(w.grad, torch.arange(3.0))
+
+
+# ---- stage-wise gradient exchange (scenesplat_amd/grad_exchange.py) -------------------------------------------------------------
+class _Staged(nn.Module):
+    """Parameter names in PT-v3m1's stage naming, one parameter that takes no part in the loss, one shared by two paths."""
+
+    def __init__(self):
+        super().__init__()
+        self.embedding = nn.Linear(4, 8)
+        self.enc = nn.ModuleDict(dict(enc0=nn.Linear(8, 8), enc1=nn.ModuleDict(dict(down=nn.Linear(8, 8), block0=nn.Linear(8, 8)))))
+        self.dec = nn.ModuleDict(dict(dec0=nn.Linear(8, 1)))
+        self.unused = nn.Linear(3, 3)
+
+    def forward(self, d):
+        h = torch.tanh(self.embedding(d["feat"]))
+        h = torch.tanh(self.enc["enc0"](h)) + h
+        h = self.enc["enc1"]["block0"](torch.tanh(self.enc["enc1"]["down"](h))) + self.enc["enc0"](h)     # enc0 used twice
+        return dict(loss=self.dec["dec0"](h).pow(2).mean())
+
+
+def _stage_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    engine.init_distributed("gloo")
+    from scenesplat_amd.grad_exchange import StageGradExchange, default_stage_of
+    torch.manual_seed(0)
+    model = _Staged()
+    ex = StageGradExchange(model)
+    assert set(ex.stages) == {"embedding", "enc.enc0", "enc.enc1", "dec.dec0", "other"}
+    assert default_stage_of("module.backbone.dec.dec0.block1.mlp.0.fc1.weight") == "dec.dec0"
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    for it, d in enumerate(_loader(3, seed=200 + rank)):
+        if it == 1:
+            opt.zero_grad(set_to_none=False)       # gradients stay the stage-buffer views: accumulated in place, no pack copy
+        else:
+            opt.zero_grad(set_to_none=True)
+        model(d)["loss"].backward()
+        ex.finish()
+        assert model.unused.weight.grad is not None and float(model.unused.weight.grad.abs().sum()) == 0.0
+        for st in ex.stages.values():
+            for p, v in zip(st["params"], st["views"]):
+                assert p.grad.data_ptr() == v.data_ptr()
+        opt.step()
+    q.put((rank, {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_stage_grad_exchange_world_size_2_gloo_matches_hand_average():
+    """One all-reduce per model stage, launched from post-accumulate hooks: both ranks end with the weights of a single process
+    that averages the two shards' gradients by hand (what DDP computes, engines/defaults.py:13-34)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stage_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda r: r[0])
+    [p.join(30) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for k in res[0][1]:
+        assert torch.allclose(torch.as_tensor(res[0][1][k]), torch.as_tensor(res[1][1][k]), atol=1e-7), k
+    torch.manual_seed(0)
+    model = _Staged()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    for a, b in zip(_loader(3, seed=200), _loader(3, seed=201)):
+        opt.zero_grad(set_to_none=True)
+        ((model(a)["loss"] + model(b)["loss"]) / 2).backward()
+        opt.step()
+    for k, v in model.state_dict().items():
+        assert torch.allclose(torch.as_tensor(res[0][1][k]), v, atol=1e-6), k
+
+
+def _stage_trainer_worker(rank, world, port, tmp, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    engine.init_distributed("gloo")
+    torch.manual_seed(rank)                   # DIFFERENT init per rank: the trainer must broadcast rank 0's weights
+    cfg = _cfg(os.path.join(tmp, f"r{rank}"))
+    cfg["hooks"] = []; cfg["grad_exchange"] = "stage"
+    tr = engine.Trainer(cfg, train_loader=_loader(3, seed=100 + rank))
+    assert not isinstance(tr.model, nn.parallel.DistributedDataParallel) and tr.grad_exchange is not None
+    tr.train()
+    q.put((rank, {k: v.numpy().copy() for k, v in tr.model.state_dict().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_trainer_with_stage_grad_exchange_equals_the_ddp_trainer():
+    """cfg["grad_exchange"] = "stage": same weights as the DDP trainer of test_ddp_world_size_2_gloo_... (hand average)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = [ctx.Process(target=_stage_trainer_worker, args=(r, world, port, tmp, q)) for r in range(world)]
+        [p.start() for p in procs]
+        res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda r: r[0])
+        [p.join(30) for p in procs]
+        assert all(p.exitcode == 0 for p in procs)
+        for k in res[0][1]:
+            assert torch.allclose(torch.as_tensor(res[0][1][k]), torch.as_tensor(res[1][1][k]), atol=1e-7), k
+        torch.manual_seed(0)
+        cfg = _cfg(os.path.join(tmp, "single")); cfg["hooks"] = []
+        tr = engine.Trainer(cfg, train_loader=_loader(3))
+        la, lb = _loader(3, seed=100), _loader(3, seed=101)
+        tr.model.train()
+        for _ in range(tr.max_epoch):
+            for a, b in zip(la, lb):
+                tr.optimizer.zero_grad(set_to_none=True)
+                ((tr.model(a)["loss"] + tr.model(b)["loss"]) / 2).backward()
+                torch.nn.utils.clip_grad_norm_(tr.model.parameters(), 1.0)
+                tr.optimizer.step(); tr.scheduler.step()
+        for k, v in tr.model.state_dict().items():
+            assert torch.allclose(torch.as_tensor(res[0][1][k]), v, atol=1e-6), k

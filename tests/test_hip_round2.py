@@ -338,6 +338,67 @@ def test_ddp_over_rccl_single_rank_matches_the_unwrapped_model():
     assert np.linalg.norm(ddp - plain) <= 2e-2 * np.linalg.norm(plain)
 
 
+def _stage_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.grad_exchange import StageGradExchange
+    from scenesplat_amd.pointcept_api import MODELS, RUNTIME
+    from scenesplat_amd.synthetic import room_chunk
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    RUNTIME.update(conv_dtype=torch.bfloat16, attn_impl=nv.ATTN_MFMA)
+    torch.manual_seed(0)
+    model = MODELS.build(dict(type="LangPretrainer", backbone=dict(type="PT-v3m1", **TINY, drop_path=0.1, shuffle_orders=True),
+                              criteria=CRIT)).cuda().train()
+    ex = StageGradExchange(model)
+    assert len(ex.stages) >= 5 and sum(len(st["params"]) for st in ex.stages.values()) == sum(p.requires_grad for p in model.parameters())
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    losses = []
+    for step in range(2):
+        d = {k: v.cuda() for k, v in room_chunk(n_side=32, seed=10 * rank + step, lang_dim=48, num_classes=4).items()}
+        d["epoch_progress"] = 0.6
+        torch.manual_seed(100 + rank + step)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = model(d)["loss"]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        ex.finish()
+        opt.step()
+        losses.append(loss.item())
+    torch.cuda.synchronize()
+    sd = {k: v.detach().float().cpu().numpy().copy() for k, v in model.state_dict().items() if v.is_floating_point() and "running_" not in k}
+    q.put((rank, sd, losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_stage_grad_exchange_two_ranks_on_the_hip_model_equal_the_ddp_weights():
+    """The round-3 gradient exchange (one all-reduce per model stage from post-accumulate hooks, scenesplat_amd/grad_exchange.py) on
+    the real HIP LangPretrainer: 2 processes share cuda:0 over gloo, different data per rank, 2 AdamW steps under bf16 autocast.
+    Both ranks end with IDENTICAL weights, and those weights are the ones torch DDP produces from the same seeds (the gradient
+    of every custom autograd Function -- grouped stage weight gradients, the fp32 arena -- reaches its stage buffer complete)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = {}
+    for name, worker in (("stage", _stage_worker), ("ddp", _ddp_worker)):
+        world, port = 2, _free_port()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+        [p.start() for p in procs]
+        res = sorted([q.get(timeout=500) for _ in range(world)], key=lambda r: r[0])
+        [p.join(60) for p in procs]
+        assert all(p.exitcode == 0 for p in procs)
+        for k in res[0][1]:
+            assert np.array_equal(res[0][1][k], res[1][1][k]), (name, k)
+        out[name] = res[0][1]
+    num = sum(float(((out["stage"][k] - out["ddp"][k]) ** 2).sum()) for k in out["ddp"]) ** 0.5
+    den = sum(float((out["ddp"][k] ** 2).sum()) for k in out["ddp"]) ** 0.5
+    print("stage exchange vs DDP after 2 AdamW steps: relative weight difference %.2e" % (num / den))
+    assert num <= 2e-3 * den          # fp32 atomics order inside the step; a missing or double-counted gradient is O(lr) = 1e-3 per element
+
+
 # ---- GPU data fast path: SphereCrop / Collect / collate (SURVEY 8f rank 3) -----------------------------------------
 def test_gpu_sphere_crop_collect_collate_against_reference_semantics():
     """pointcept/datasets/transform.py:1420-1548 (SphereCrop random / center), :320-352 (Collect) and
