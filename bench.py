@@ -21,6 +21,10 @@ sys.path.insert(0, ROOT)
 # before torch is imported and long before any GPU call: the host driver only supports dmabuf IPC (RCCL / tensor sharing across
 # processes fails otherwise), and the HSA runtime reads the variable once, when it initialises
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# HIP maps streams onto 4 hardware queues by default.  With a process group initialised (RCCL's streams) the plan-building side
+# stream came to share a queue with the compute stream: its device->host round trips then waited for the whole step and the host
+# blocked 35 ms per step (one-rank rehearsal, round 3: 42.2 -> 39.5 ms/step with 8 queues).  Read once, when HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -377,7 +381,8 @@ def main():
         from scenesplat_amd.grad_exchange import StageGradExchange
         for t_ in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t_.data, src=0)
-        exchange = StageGradExchange(model, force=force_ddp)
+        # packed form (no host callbacks inside the backward): the step stays a hipGraph replay, the all-reduces follow it
+        exchange = StageGradExchange(model, force=force_ddp, hooks=(args.graph == "off"))
     if args.fixture == "uniform":
         from scenesplat_amd.synthetic import uniform_chunk
         data = {k: v.to(dev) for k, v in uniform_chunk(seed=rank).items()}
@@ -400,24 +405,39 @@ def main():
         # backward from the seeded random cotangent, fed directly as the output gradient (no loss kernels)
         torch.autograd.backward(out.feat, grad_tensors=t["cot"])
         if exchange is not None:
-            exchange.finish()
+            if exchange._hooks:
+                exchange.finish()          # eager form: the stage all-reduces were issued by hooks during the backward
+            else:
+                exchange.pack()            # packed form: captured with the step; the all-reduces follow the replay (step())
         return {"feat": out.feat}
 
     # Steady state (scenesplat_amd/steady_state.py): every chunk of the room has the same plan SHAPE, so after two eager
     # steps the ~1,100 launches of forward + backward are captured in a hipGraph and later steps replay it -- the plan is
     # still built anew every step (on the side stream) and copied into the captured plan's tensors; every kernel still
     # runs.  With more than one rank the step stays eager: DDP's bucket hooks are host callbacks.
-    use_graph = (args.graph == "on" or (args.graph == "auto" and world == 1)) and not force_ddp
+    # N > 1 (round 3): with the stage exchange in its packed form the step is replayed as a graph on every rank too
+    use_graph = (args.graph == "on" or (args.graph == "auto" and (world == 1 or args.exchange == "stage"))) and not (force_ddp and args.exchange == "ddp") \
+        and not (world > 1 and args.exchange == "ddp")
     from scenesplat_amd.steady_state import SteadyStateStep
     steady = SteadyStateStep(fwd_bwd, list(model.parameters()), warmup=1, enabled=use_graph)
 
+    seg = {"zero": 0.0, "steady": 0.0, "reduce": 0.0, "plan": 0.0} if os.environ.get("SS_BENCH_HOST_SEGMENTS") else None
+
     def step():
+        t_a = time.perf_counter()
         net.zero_grad(set_to_none=True)
         plan, state["plan"] = state["plan"], None
+        t_b = time.perf_counter()
         steady(plan, {"feat": data["feat"], "cot": cot16})
+        t_c = time.perf_counter()
+        if exchange is not None and not exchange._hooks:
+            exchange.reduce()
+        t_d = time.perf_counter()
         # SS_BENCH_REUSE_PLAN=1 is a DIAGNOSTIC (host- vs GPU-bound?): it skips the per-step plan build and the line it
         # prints is not the metric
         state["plan"] = plan if os.environ.get("SS_BENCH_REUSE_PLAN") == "1" else model.prepare_plan(data, stream=side)
+        if seg is not None:      # DIAGNOSTIC: where the host spends a step (ms, summed over all steps incl. warm-up)
+            seg["zero"] += t_b - t_a; seg["steady"] += t_c - t_b; seg["reduce"] += t_d - t_c; seg["plan"] += time.perf_counter() - t_d
 
     def log(msg):
         if rank == 0:
@@ -470,6 +490,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
+    if rank == 0 and seg is not None:
+        log("host segments over all steps (s): " + ", ".join("%s %.3f" % kv for kv in seg.items()))
+    if rank == 0 and exchange is not None and exchange.prof is not None:
+        log("exchange host time per step: launches %.2f ms, finish %.2f ms (%d steps)" % (
+            1e3 * exchange.prof["launch_s"] / max(1, exchange.prof["steps"]), 1e3 * exchange.prof["finish_s"] / max(1, exchange.prof["steps"]), exchange.prof["steps"]))
     if rank == 0:
         res = {
             "metric": "Gaussians/s encoder fwd+bwd, 102k-pt chunks", "value": world * n * args.steps / dt,

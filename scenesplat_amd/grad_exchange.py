@@ -17,9 +17,18 @@ copies; no host callback per parameter beyond a counter.
     ex = StageGradExchange(model)            # after the model is on its device, process group initialised
     loss.backward(); ex.finish()             # every step; then optimizer.step()
 
-World size 1 (or no process group): the hooks are not installed and finish() is a no-op.
+hooks=False ("packed" mode, for steps replayed as a hipGraph -- steady_state.py -- where no host callback can run inside the
+backward): the step itself ends with ex.pack() (one multi-tensor copy per stage, captured with the step), and after the replay
+ex.reduce() issues the stage all-reduces and finishes.  Nothing overlaps the backward then (about 2-3 ms of exposed all-reduce at
+8 ranks for the 367 MB of this model), but the host enqueues ~170 calls per step instead of ~1,300: measured on one rank, the
+eager step under either DDP or the hook form is HOST-bound (44-47 ms/step of enqueue against 39 ms of GPU work), so the packed form
+is what bench.py uses for N > 1.
+
+World size 1 (or no process group): nothing is installed and every method is a no-op.
 """
+import os
 import re
+import time
 
 import torch
 import torch.distributed as dist
@@ -36,11 +45,12 @@ def default_stage_of(name):
 
 
 class StageGradExchange:
-    def __init__(self, model, process_group=None, stage_of=default_stage_of, average=True, force=False):
+    def __init__(self, model, process_group=None, stage_of=default_stage_of, average=True, force=False, hooks=True):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.average = average
         self.stages = {}              # label -> dict(params, views, flat, pending, handle)
+        self.prof = {"hooks": 0, "launch_s": 0.0, "finish_s": 0.0, "steps": 0} if os.environ.get("SS_EXCHANGE_PROFILE") else None
         self._order = []
         self._hooks = []
         self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())     # force: one-rank rehearsal
@@ -62,18 +72,27 @@ class StageGradExchange:
             st["flat"] = torch.zeros(tot, dtype=dt, device=dev)
             st["views"] = [st["flat"][o:o + p.numel()].view_as(p) for o, p in zip(offs, st["params"])]
             st["count"], st["handle"] = 0, None
-            for p in st["params"]:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(st)))
+            if hooks:
+                for p in st["params"]:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(st)))
 
     def _make_hook(self, st):
         def hook(_param):
             st["count"] += 1
             if st["count"] == len(st["params"]):
-                self._launch(st)
+                if self.prof is not None:
+                    t0 = time.perf_counter(); self._launch(st); self.prof["launch_s"] += time.perf_counter() - t0
+                else:
+                    self._launch(st)
         return hook
 
     def _launch(self, st):
         """Every gradient of the stage is final: pack (skipping those that already live in the stage buffer) and all-reduce."""
+        self._pack(st)
+        st["handle"] = dist.all_reduce(st["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._order.append(st)
+
+    def _pack(self, st):
         src, dst = [], []
         for p, v in zip(st["params"], st["views"]):
             g = p.grad
@@ -83,14 +102,37 @@ class StageGradExchange:
                 src.append(g); dst.append(v)
         if src:
             torch._foreach_copy_(dst, src)
-        st["handle"] = dist.all_reduce(st["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._order.append(st)
+
+    def pack(self):
+        """Packed mode, inside the (captured) step after backward(): every stage's gradients into its buffer."""
+        if not self.active:
+            return
+        for st in self.stages.values():
+            self._pack(st)
+
+    def reduce(self):
+        """Packed mode, after the step (outside any capture): all-reduce every stage buffer, average, point param.grad at the slots."""
+        if not self.active:
+            return
+        # stream-synchronous collectives (async_op=False): with RCCL the call returns once the all-reduce is enqueued and the compute
+        # stream is made to wait for it -- nothing overlaps here anyway, and no Work handle has to be waited for on the host
+        t0 = time.perf_counter()
+        for st in self.stages.values():
+            dist.all_reduce(st["flat"], op=dist.ReduceOp.SUM, group=self.group)
+            if self.average and self.world > 1:
+                st["flat"].div_(self.world)
+            for p, v in zip(st["params"], st["views"]):
+                p.grad = v
+            st["count"], st["handle"] = 0, None
+        if self.prof is not None:
+            self.prof["finish_s"] += time.perf_counter() - t0; self.prof["steps"] += 1
 
     def finish(self):
         """Call after backward(): launches the stages whose count never completed (parameters without a gradient this step), waits
         for every collective, averages, and points each param.grad at its slot."""
         if not self.active:
             return
+        t0 = time.perf_counter()
         for st in self.stages.values():
             if st["handle"] is None:
                 self._launch(st)
@@ -102,6 +144,8 @@ class StageGradExchange:
                 p.grad = v
             st["count"], st["handle"] = 0, None
         self._order = []
+        if self.prof is not None:
+            self.prof["finish_s"] += time.perf_counter() - t0; self.prof["steps"] += 1
 
     def zero_grad(self):
         """set_to_none for every managed parameter (the slots are overwritten by the next pack)."""

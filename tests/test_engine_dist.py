@@ -172,13 +172,13 @@ class _Staged(nn.Module):
         return dict(loss=self.dec["dec0"](h).pow(2).mean())
 
 
-def _stage_worker(rank, world, port, q):
+def _stage_worker(rank, world, port, q, hooks=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     engine.init_distributed("gloo")
     from scenesplat_amd.grad_exchange import StageGradExchange, default_stage_of
     torch.manual_seed(0)
     model = _Staged()
-    ex = StageGradExchange(model)
+    ex = StageGradExchange(model, hooks=hooks)
     assert set(ex.stages) == {"embedding", "enc.enc0", "enc.enc1", "dec.dec0", "other"}
     assert default_stage_of("module.backbone.dec.dec0.block1.mlp.0.fc1.weight") == "dec.dec0"
     opt = torch.optim.SGD(model.parameters(), lr=0.1)
@@ -188,7 +188,10 @@ def _stage_worker(rank, world, port, q):
         else:
             opt.zero_grad(set_to_none=True)
         model(d)["loss"].backward()
-        ex.finish()
+        if hooks:
+            ex.finish()
+        else:
+            ex.pack(); ex.reduce()             # the packed form of graph-replayed steps: pack inside the step, all-reduce after it
         assert model.unused.weight.grad is not None and float(model.unused.weight.grad.abs().sum()) == 0.0
         for st in ex.stages.values():
             for p, v in zip(st["params"], st["views"]):
@@ -200,13 +203,15 @@ def _stage_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(180)
-def test_stage_grad_exchange_world_size_2_gloo_matches_hand_average():
-    """One all-reduce per model stage, launched from post-accumulate hooks: both ranks end with the weights of a single process
-    that averages the two shards' gradients by hand (what DDP computes, engines/defaults.py:13-34)."""
+@pytest.mark.parametrize("hooks", [True, False])
+def test_stage_grad_exchange_world_size_2_gloo_matches_hand_average(hooks):
+    """One all-reduce per model stage -- launched from post-accumulate hooks during the backward, or (hooks=False) packed at the end
+    of the step and reduced after it: both ranks end with the weights of a single process that averages the two shards'
+    gradients by hand (what DDP computes, engines/defaults.py:13-34)."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_stage_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_stage_worker, args=(r, world, port, q, hooks)) for r in range(world)]
     [p.start() for p in procs]
     res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda r: r[0])
     [p.join(30) for p in procs]
