@@ -4,6 +4,9 @@
 //         scripts/ubench/attn_hm_bench.hip -o scripts/ubench/bin/attn_hm_bench
 // HM_ABL bits (forward): 1 no DMA, 2 no barrier, 4 exp -> mul, 8 no max / rescale, 16 no PV MFMAs, 32 no QK^T MFMAs, 64 no stores
 #include "../../scenesplat_amd/csrc/attention_hm.hip"
+// the C-ABI wrapper at the end of attention_hm.hip calls the borrowed-slot fix-up of attention_simt.hip; the harness drives the
+// kernels directly and checks the side buffer itself
+int ss_attn_fix_borrowed(const int32_t*, const int32_t*, int64_t, const void*, void*, int, int, hipStream_t) { return SS_OK; }
 #include <cstdio>
 #include <cstring>
 #include <cmath>
