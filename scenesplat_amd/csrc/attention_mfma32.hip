@@ -10,7 +10,7 @@
 //     product uses; no v_add chain, no extra MFMA, and the lazy rescale of O^T rescales it too;
 //   * the running maximum moves only when a tile's maximum exceeds it by more than FA32_THR (exp2 units): after the
 //     first tiles the O^T rescale (32 multiplies) is skipped almost always; P <= 2^THR keeps bf16's relative precision;
-//   * one accumulator tile = 32 queries x 32 keys per wave; 4 waves = 128 queries per workgroup, 64 keys per barrier;
+//   * one accumulator tile = 32 queries x 32 keys per wave; FA32_WAVES = 8 waves = 256 queries per workgroup, 64 keys per barrier;
 //   * K image rows padded to an odd number of 16-byte chunks (conflict-free ds_read_b128 without a swizzle), V image
 //     rows at a stride of 192 B (64 B for d <= 32): the four rows of a transposed read land in distinct 64-byte bank
 //     groups (ds_read_b64_tr_b16 conflict-free);

@@ -3,15 +3,10 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I scenesplat_amd/csrc [-DFA32_ABL=m] \
 //         scripts/ubench/attn_bench.hip -o attn_bench
 // FA32_ABL bits: 1 no global loads / LDS staging writes, 2 no barrier, 4 exp -> mul, 8 no max / rescale,
-//                16 no PV MFMAs, 32 no QK^T MFMAs.   -DFA32_PERSIST times the rejected persistent variant,
-//                -DFA32_CLOCK reads the in-kernel clock stamps.   (results are wrong by construction; only the time is read)
+//                16 no PV MFMAs, 32 no QK^T MFMAs.   -DFA32_CLOCK reads the in-kernel clock stamps.
+//                (ablation results are wrong by construction; only the time is read)
 #include "../../scenesplat_amd/csrc/attention_mfma32.hip"
-#ifdef FA32_PERSIST
-#include "attn_fwd_persistent.inc"   // rejected persistent variant (see its header)
-#define FWD_LAUNCH fa32_persistent_launch
-#else
 #define FWD_LAUNCH ss_attn_fwd_mfma32
-#endif
 #include <cstdio>
 #include <cstring>
 #include <cmath>
