@@ -35,9 +35,6 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 g8_bf8_t;
 #define G8_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 #define G8_TAPS_MAX 27
-#ifndef G8_KCHUNK_DEFAULT
-#define G8_KCHUNK_DEFAULT 0      // channels per K-walk chunk of the conv (0 = whole rows); see g8_launch
-#endif
 #define G8_ZERO_ELEMS 4096
 
 #ifndef G8_STAGGER
@@ -65,7 +62,7 @@ template <bool GATHER, typename OutT, bool HM = false>
 __global__ void __launch_bounds__(512)
 k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, const float* __restrict__ bias,
         const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowperm, OutT* __restrict__ out, int M, int K,
-        int N, int taps, int ntn, int kchunk, int hm_c = 0, int hm_d = 0, float hm_scale = 1.f) {
+        int N, int taps, int ntn, int hm_c = 0, int hm_d = 0, float hm_scale = 1.f) {
   __shared__ __attribute__((aligned(16))) char smem[G8_LDS_BYTES];   // ONE object: tiles + rulebook slice
   int32_t* nbr_s = reinterpret_cast<int32_t*>(smem + G8_OFF_NBR);
   int32_t* rowid_s = reinterpret_cast<int32_t*>(smem + G8_OFF_ROWID);
@@ -81,7 +78,6 @@ k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__
   const int m0 = (L / ntn) * 256, n0 = (L % ntn) * 256;
 
   unsigned rem = 0u;       // taps still to do after the current one (GATHER)
-  unsigned mask_all = 0u;  // the tile's active taps
   int tap = 0;
   if (GATHER) {
     if (tid < 256) {
@@ -99,7 +95,6 @@ k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__
     }
     __syncthreads();
     rem = __builtin_amdgcn_readfirstlane(*mask_s);
-    mask_all = rem;
   }
   const int ksteps = K >> 6;
   int T;                                        // K-tiles of this workgroup
@@ -147,7 +142,6 @@ k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__
       pB[h][j] = W + (int64_t)col * taps * K + lc8;
     }
   int kc = 0;                                    // channel offset of the tile being staged
-  int kbase = 0, kend = GATHER ? min(kchunk, K) : K;   // current channel chunk (GATHER)
   int64_t boff = (int64_t)tap * K;               // tap offset in W rows
   load_rows(tap);
   int staged = 0;                                // index of the tile the state describes
@@ -156,13 +150,11 @@ k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__
     ++staged;
     kc += 64;
     if (GATHER) {
-      // K walk of the conv: channel chunks of `kchunk` (a multiple of 64; kchunk >= K: one chunk) outermost, the tile's
-      // active taps inside a chunk, 64-channel K-tiles innermost.  With one chunk the rows of a tap are streamed whole
-      // (1.5 KB per site and tap: ~4 MB per tap step over the tiles an XCD runs -- the next tap's re-reads of the same rows
-      // miss its L2); a smaller chunk keeps the pieces of the tile's rows L2-resident across the taps.
-      if (kc == kend) {
-        if (rem == 0u) { kbase = kend; kend = min(kbase + kchunk, K); rem = mask_all; }
-        kc = kbase;
+      // K walk of the conv: the tile's active taps outermost, a tap's whole rows (64-channel K-tiles) innermost.  (Walking channel
+      // chunks outermost, so that a row piece wanted by up to nine (site, tap) pairs stays L2-resident, was built in round 2 and is
+      // monotonically slower the smaller the chunk: long contiguous row reads matter more than the re-use -- DESIGN.md section 4.)
+      if (kc == K) {
+        kc = 0;
         tap = __builtin_ctz(rem); rem &= rem - 1u;
         boff = (int64_t)tap * K;
         load_rows(tap);
@@ -321,19 +313,13 @@ template <bool GATHER>
 static int g8_launch(const void* a, const void* w, const float* bias, const int32_t* nbr, const int32_t* rowperm, void* out,
                      int64_t m, int k, int n, int taps, int out_dtype, hipStream_t stream) {
   if (!ss_gemm8_ok(m, k, n, taps)) return SS_ERR_ARG;
-  // SS_CONV_KCHUNK (diagnostic A/B switch, read once): channels per chunk of the conv's K walk, a multiple of 64; 0 = the
-  // whole row per tap.  (64 = the round-2 "tap inner" experiment.)
-  static const int kchunk_env = [] { const char* e = getenv("SS_CONV_KCHUNK"); return e ? atoi(e) : -1; }();
-  int kchunk = kchunk_env >= 0 ? kchunk_env : G8_KCHUNK_DEFAULT;
-  if (kchunk <= 0 || kchunk > k) kchunk = k;
-  kchunk = (kchunk + 63) & ~63;
   const int ntm = ss_div_up(m, 256), ntn = ss_div_up(n, 256);
   dim3 grid(ntm * ntn), block(512);
   const unsigned short* A = (const unsigned short*)a; const unsigned short* Wp = (const unsigned short*)w;
   if (out_dtype == SS_BF16)
-    SS_LAUNCH((k_gemm8<GATHER, unsigned short>), grid, block, 0, stream, A, Wp, bias, nbr, rowperm, (unsigned short*)out, (int)m, k, n, taps, ntn, kchunk);
+    SS_LAUNCH((k_gemm8<GATHER, unsigned short>), grid, block, 0, stream, A, Wp, bias, nbr, rowperm, (unsigned short*)out, (int)m, k, n, taps, ntn);
   else if (out_dtype == SS_F32)
-    SS_LAUNCH((k_gemm8<GATHER, float>), grid, block, 0, stream, A, Wp, bias, nbr, rowperm, (float*)out, (int)m, k, n, taps, ntn, kchunk);
+    SS_LAUNCH((k_gemm8<GATHER, float>), grid, block, 0, stream, A, Wp, bias, nbr, rowperm, (float*)out, (int)m, k, n, taps, ntn);
   else
     return SS_ERR_ARG;
   return SS_OK;
@@ -364,7 +350,7 @@ extern "C" int ss_linear_fwd_headmajor(const void* x, const int32_t* row_index, 
   const int ntm = ss_div_up(m, 256), ntn = ss_div_up(n_out, 256);
   dim3 grid(ntm * ntn), block(512);
   SS_LAUNCH((k_gemm8<false, unsigned short, true>), grid, block, 0, stream, (const unsigned short*)x, (const unsigned short*)weight,
-            bias, (const int32_t*)nullptr, row_index, (unsigned short*)out_hm, (int)m, k, n_out, 1, ntn, k, channels, head_dim,
+            bias, (const int32_t*)nullptr, row_index, (unsigned short*)out_hm, (int)m, k, n_out, 1, ntn, channels, head_dim,
             sec0_scale);
   return SS_OK;
 }

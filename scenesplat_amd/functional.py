@@ -215,12 +215,7 @@ class _SubMConv3dFused(torch.autograd.Function):
                 dx = (dx * is_w.unsqueeze(1)).to(in_dtype)
         if ctx.needs_input_grad[1]:
             blocks = ctx.blocks_fn() if ctx.blocks_fn is not None else nv.subm_block_lists(nbr, rowperm)
-            if _Defer.open and w_dtype == torch.float32 and x.shape[1] == cin:
-                dwb = nv.zeros_f32(w.numel(), x.device).view(w.shape)
-                _defer(lambda: nv.subm_conv_wgrad(x, g, nbr, rowperm, blocks, out=dwb), (x, g, dwb, nbr, rowperm) + tuple(blocks))
-                dw = dwb.view(w_shape)
-            else:
-                dw = nv.subm_conv_wgrad(x, g, nbr, rowperm, blocks)[:, :, :cin].reshape(w_shape).to(w_dtype)
+            dw = nv.subm_conv_wgrad(x, g, nbr, rowperm, blocks)[:, :, :cin].reshape(w_shape).to(w_dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = g.sum(0, dtype=torch.float32).to(w_dtype)
         return dx, dw, db, None, None, None, None
@@ -495,95 +490,6 @@ def bf16_of(p):
     return p.to(torch.bfloat16)
 
 
-# ---- deferred weight gradients -----------------------------------------------------------------------------
-# 87 % of the FLOPs sit in the last decoder stage (full resolution); the rest of the backward pass is ~1,000 small
-# kernels on the pooled levels that leave most CUs idle.  The weight gradients of that last stage do not feed the
-# backward chain, so they are QUEUED while backward runs through the stage and launched on a side stream when the
-# chain leaves it (the model plants a marker there): they then fill the idle CUs under the small-level chain.
-# Autograd receives the (zero-filled, fp32) accumulator at once; the kernel adds into it later; the main stream joins
-# the side stream in an end-of-backward engine callback, before anything can read a .grad.
-# Not valid with per-parameter gradient hooks that read the value during backward (DDP): callers disable it there.
-class _Defer:
-    enabled = os.environ.get("SS_DEFER_WGRAD", "0") != "0"   # opt-in: measured +0.4 ms/step (worse) on room-102400
-    open = False
-    queue = []
-    stream = None
-    armed = False
-
-
-def _side_stream():
-    """Stream for the deferred launches.  SS_DEFER_CU_MASK (hex word repeated over the 256 CUs) restricts it to a CU
-    subset through hipExtStreamCreateWithCUMask -- measured: half or a quarter of the CUs make the step 8-10 ms SLOWER
-    (the deferred work then outlasts the chain it hides under), so the default is an ordinary low-priority stream."""
-    word = int(os.environ.get("SS_DEFER_CU_MASK", "0"), 16)
-    if word:
-        import ctypes
-        mask = (ctypes.c_uint32 * 8)(*([word] * 8))
-        out = ctypes.c_void_p(0)
-        if nv.lib().ss_stream_create_cu_mask(8, mask, ctypes.byref(out)) == 0 and out.value:
-            return torch.cuda.ExternalStream(out.value)
-    prio = int(os.environ.get("SS_DEFER_PRIORITY", "0"))
-    return torch.cuda.Stream(priority=prio)
-
-
-def defer_open():
-    """Model forward (training): wgrads issued from now on are queued until defer_flush()."""
-    _Defer.open = bool(_Defer.enabled and torch.is_grad_enabled()
-                       and not (torch.distributed.is_available() and torch.distributed.is_initialized()
-                                and torch.distributed.get_world_size() > 1))
-    if not _Defer.open:
-        _Defer.queue.clear()
-
-
-def _defer_join():
-    """End of the backward pass: launch what is still queued and make the main stream wait for the side stream."""
-    _Defer.armed = False
-    defer_flush(close=True)
-    if _Defer.stream is not None:
-        torch.cuda.current_stream().wait_stream(_Defer.stream)
-
-
-def defer_flush(close=True):
-    if close:
-        _Defer.open = False
-    if not _Defer.queue:
-        return
-    if _Defer.stream is None:
-        _Defer.stream = _side_stream()
-    side, main = _Defer.stream, torch.cuda.current_stream()
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        for run, tensors in _Defer.queue:
-            run()
-            for t in tensors:
-                t.record_stream(side)
-    _Defer.queue.clear()
-
-
-def _defer(run, tensors):
-    _Defer.queue.append((run, tensors))
-    if not _Defer.armed:      # we are inside a backward node: the engine runs the callback when the pass completes
-        _Defer.armed = True
-        torch.autograd.Variable._execution_engine.queue_callback(_defer_join)
-
-
-class _DeferMarker(torch.autograd.Function):
-    """Identity; its backward marks the point where the backward chain leaves the full-resolution decoder stage."""
-
-    @staticmethod
-    def forward(ctx, x):
-        return x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, g):
-        defer_flush(close=True)
-        return g
-
-
-def defer_marker(x):
-    return _DeferMarker.apply(x) if (_Defer.enabled and x.requires_grad) else x
-
-
 # ---- grouped weight gradients of a stage ------------------------------------------------------------------------------
 # On the pooled levels a Linear weight gradient is a 20-30 us, latency-bound launch on 12-20 workgroups, and a stage has
 # 5 per block (86 such launches = 2.7 ms per step).  They do not feed the backward chain, so the blocks of a stage QUEUE
@@ -646,8 +552,6 @@ def reset_state():
     """Forget everything a forward pass leaves between its calls (the open stage, queued weight gradients, the remembered
     head sums): called after a forward / backward that ended in an exception, e.g. a refused hipGraph capture."""
     stage_end()
-    _Defer.open = _Defer.armed = False
-    _Defer.queue.clear()
     _HEAD_CACHE.clear()
 
 
@@ -695,11 +599,6 @@ def _linear_backward(x, w16, dgrad_nt, w_dtype, has_bias, stage, dy, need_x, nee
                 # queued: the stage's identity node launches the whole group when the backward chain leaves the stage
                 dw, db_ = nv.linear_wgrad_alloc(k, dy.shape[1], want_db, x.device)
                 stage.queue.append((x, dy, dw, db_))
-                if want_db:
-                    db, want_db = db_, False
-            elif _Defer.open and w_dtype == torch.float32:
-                dw, db_ = nv.linear_wgrad_alloc(k, dy.shape[1], want_db, x.device)
-                _defer(lambda: nv.linear_wgrad_into(x, dy, dw, db_), (x, dy, dw))
                 if want_db:
                     db, want_db = db_, False
             elif want_db:                    # column sums of dy ride along in the wgrad kernel

@@ -503,8 +503,6 @@ class PointTransformerV3(PointModule):
                 dec = getattr(self.dec, f"dec{s}")
                 SF.stage_begin(self._stage_linears(dec), levels[s].n)
                 x, conv_in = dec.up(x, skips[s], levels[s + 1])
-                if s == 0 and self.training:
-                    x = SF.defer_marker(x)       # backward leaves the full-resolution stage here: launch its queued wgrads
                 xb = None
                 for i in range(self.dec_depths[s]):
                     wc = self._want_copy and conv_dtype_for(x.shape[1]) == torch.bfloat16
@@ -512,8 +510,6 @@ class PointTransformerV3(PointModule):
                                                       wc and i + 1 < self.dec_depths[s])
                 SF.stage_end()
             lv = 0
-            if self.training:
-                SF.defer_open()                  # backward starts in dec0: queue its weight gradients (see SF._Defer)
         out = Point(feat=x, plan=plan, level=lv)
         for k in ("coord", "grid_coord", "offset"):
             if lv == 0 and dict.__contains__(point, k):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """A/B of a runtime switch inside ONE process (interleaved blocks; run-to-run noise of separate processes is +-2 ms):
-   python scripts/ab_step.py defer|shadows|im2col|arena [blocks] [steps]"""
+   python scripts/ab_step.py attn_hm|group_cast|shadows|im2col|... [blocks] [steps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +8,7 @@ from scenesplat_amd import native as nv, functional as SF
 from scenesplat_amd.pointcept_api import MODELS, RUNTIME
 from scenesplat_amd.synthetic import LANG_PTV3, room_chunk
 
-which = sys.argv[1] if len(sys.argv) > 1 else "defer"
+which = sys.argv[1] if len(sys.argv) > 1 else "attn_hm"
 blocks = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 from scenesplat_amd.pointcept_api import bench_runtime
@@ -21,9 +21,7 @@ state = {"plan": model.prepare_plan(data, stream=side)}
 
 
 def setter(on):
-    if which == "defer":
-        SF._Defer.enabled = on
-    elif which == "shadows":
+    if which == "shadows":
         RUNTIME["param_shadows"] = on
     elif which == "im2col":
         SF.CONV_IM2COL_MAX_SITES = 8192 if on else 0
