@@ -418,7 +418,7 @@ def main():
     # N > 1 (round 3): with the stage exchange in its packed form the step is replayed as a graph on every rank too
     use_graph = (args.graph == "on" or (args.graph == "auto" and (world == 1 or args.exchange == "stage"))) and not (force_ddp and args.exchange == "ddp") \
         and not (world > 1 and args.exchange == "ddp")
-    from scenesplat_amd.steady_state import SteadyStateStep
+    from scenesplat_amd.steady_state import CaptureInvalidated, SteadyStateStep
     steady = SteadyStateStep(fwd_bwd, list(model.parameters()), warmup=1, enabled=use_graph)
 
     seg = {"zero": 0.0, "steady": 0.0, "reduce": 0.0, "plan": 0.0} if os.environ.get("SS_BENCH_HOST_SEGMENTS") else None
@@ -428,7 +428,14 @@ def main():
         net.zero_grad(set_to_none=True)
         plan, state["plan"] = state["plan"], None
         t_b = time.perf_counter()
-        steady(plan, {"feat": data["feat"], "cot": cot16})
+        try:
+            steady(plan, {"feat": data["feat"], "cot": cot16})
+        except CaptureInvalidated as e:
+            # the capture could not be completed (steady_state.py abandons it and switches itself to eager launches): the step is
+            # repeated eagerly and the run goes on -- a failed capture must not take a scaling run down
+            log("hipGraph capture abandoned, eager from here: %s" % e)
+            net.zero_grad(set_to_none=True)
+            steady(plan, {"feat": data["feat"], "cot": cot16})
         t_c = time.perf_counter()
         if exchange is not None and not exchange._hooks:
             exchange.reduce()
