@@ -281,6 +281,7 @@ k_attn_hm_fwd(const unsigned short* __restrict__ hm, int64_t NP, const int32_t* 
   asm volatile("" : "+v"(srow));
 #pragma unroll
   for (int ks = 0; ks < A::NKS; ++ks) asm volatile("" : "+v"(qf[ks]));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ones plane is written before the first barrier releases its readers
   unsigned slot_off = 0;                                   // byte offset of tile t's ring slot
   for (int t = 0; t < ntiles; ++t) {
     // tile t has landed (own pieces: all but the NPW youngest), then everybody's; the barrier also says that every wave is
