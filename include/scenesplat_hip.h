@@ -181,6 +181,21 @@ int ss_subm_conv_wgrad(const void* in, const void* dout, const int32_t* nbr, con
                        const int32_t* blk_count, const int32_t* blk_list, float* dweight, int64_t n, int cin, int cout,
                        int taps, ss_stream_t stream);
 
+/* ---- first-stage submanifold conv in exact fp32 on v_mfma_f32_32x32x2_f32 (csrc/subm_f32.hip) ---------------------
+ * Replaces spconv.SubMConv3d (pointcept/models/modules.py:64-75, fp32 under AMP) for the 32-channel stage:
+ * stem (ptv3:572-590 Embedding, k = 5, 6..11 -> 32) and the enc0 cpe convs (ptv3:271-289, k = 3, 32 -> 32).
+ * in (n, cin_padded) f32 with cin_padded 16 or 32 (zero-padded channels); cout == 32.
+ * wq = weights re-laid [tap][cin_padded / 8][2][32 co][4] f32: wq[t][q][h][co][e] = W[co][t][8 q + 4 h + e].
+ * nbr_walk (taps, n): the rulebook in WALK order, nbr_walk[t][k] = nbr[t][rowperm[k]] (rowperm NULL: nbr itself).
+ * dgrad = the same entry on (dout, tap-mirrored transposed weights). */
+int ss_subm_f32_ok(int cin_padded, int cout);
+int ss_subm_f32_fwd(const float* in, const float* wq, const float* bias, const int32_t* nbr_walk, const int32_t* rowperm,
+                    float* out, int64_t n, int cin_padded, int cout, int taps, ss_stream_t stream);
+/* dweight (32, taps, cin) f32 ACCUMULATED into (caller zeroes it); blk_* from ss_subm_block_lists with the same rowperm */
+int ss_subm_f32_wgrad(const float* in, const float* dout, const int32_t* nbr_walk, const int32_t* rowperm,
+                      const int32_t* blk_count, const int32_t* blk_list, float* dweight, int64_t n, int cin_padded,
+                      int cin, int cout, int taps, ss_stream_t stream);
+
 /* ---- fused residual add (+ DropPath row scale) + LayerNorm (ptv3:318-338 seams) ------------------------
  * v = x + rowscale*y; xout = v (f32/bf16) [+ bf16 copy]; h = LN(v)*gamma+beta.  NULL = absent.  C % 4 == 0, C <= 1024. */
 int ss_add_layernorm_fwd(const void* x, int x_dtype, const void* y, int y_dtype, const float* rowscale,

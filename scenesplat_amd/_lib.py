@@ -70,6 +70,9 @@ PROTOTYPES = {
     "ss_subm_conv_fwd_splitk": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "ss_subm_block_lists": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p]),
     "ss_subm_conv_wgrad": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
+    "ss_subm_f32_ok": (c_i, [c_i, c_i]),
+    "ss_subm_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
+    "ss_subm_f32_wgrad": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "ss_add_layernorm_fwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_p]),
     "ss_add_layernorm_bwd_blocks": (c_i, [c_i64]),
     "ss_group_partial_sums": (c_i, [c_p, c_p, c_i, c_i, c_p]),

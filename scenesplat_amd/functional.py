@@ -276,6 +276,47 @@ class _SubMConv3dSplit(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+class _SubMConv3dF32(torch.autograd.Function):
+    """The 32-channel first stage in EXACT fp32 on the matrix cores (csrc/subm_f32.hip, v_mfma_f32_32x32x2_f32): what the reference
+    computes for this op under AMP (spconv in fp32, pointcept/models/modules.py:64-75) without the 3x products and the hi/lo operand
+    copies of _SubMConv3dSplit.  Eligible: 32 output channels, at most 32 input channels, no duplicate voxels; the input gradient
+    needs 32 input channels (the stem's input is data and takes none)."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias, nbr, rowperm, blocks_fn, walk_fn):
+        taps, n = nbr.shape
+        cout, cin = weight.shape[0], weight.shape[-1]
+        cp = 16 if cin <= 16 else 32
+        ctx.orig_nbr = nbr if blocks_fn is None else None
+        nbr = walk_fn() if walk_fn is not None else nv.subm_walk_rulebook(nbr, rowperm)     # walk order from here on
+        x = feat.float()
+        if cp != cin:
+            x = torch.nn.functional.pad(x, (0, cp - cin))
+        x = x.contiguous()
+        w = weight.float().reshape(cout, taps, cin)
+        out = nv.subm_f32_fwd(x, nv.subm_f32_weight_layout(w), None if bias is None else bias.float().contiguous(), nbr, rowperm)
+        ctx.save_for_backward(x, w, nbr, rowperm)
+        ctx.meta = (feat.dtype, weight.dtype, weight.shape, cin, bias is not None)
+        ctx.blocks_fn = blocks_fn
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, nbr, rowperm = ctx.saved_tensors
+        in_dtype, w_dtype, w_shape, cin, has_bias = ctx.meta
+        g = dout.float().contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = nv.subm_f32_fwd(g, nv.subm_f32_weight_layout(w, mirror=True), None, nbr, rowperm).to(in_dtype)
+        if ctx.needs_input_grad[1]:
+            blocks = ctx.blocks_fn() if ctx.blocks_fn is not None else nv.subm_block_lists(ctx.orig_nbr, rowperm)
+            dw = nv.subm_f32_wgrad(x, g, nbr, rowperm, blocks, cin).reshape(w_shape).to(w_dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = g.sum(0, dtype=torch.float32).to(w_dtype)
+        return dx, dw, db, None, None, None, None
+
+
+CONV_F32_MFMA = os.environ.get("SS_CONV_F32_MFMA", "1") != "0"      # A/B switch against the bf16x3 split (scripts/ab_step.py)
 CONV_IM2COL_MAX_SITES = int(os.environ.get("SS_CONV_IM2COL_MAX", "8192"))
 
 
@@ -287,13 +328,17 @@ def _mm_f32(a, b):
         return torch.mm(a, b).float()
 
 
-def subm_conv3d(feat, weight, bias, nbr, has_dup=False, compute_dtype=torch.float32, rowperm=None, blocks_fn=None):
+def subm_conv3d(feat, weight, bias, nbr, has_dup=False, compute_dtype=torch.float32, rowperm=None, blocks_fn=None, walk_fn=None):
     """weight (Cout, k, k, k, Cin) as in the reference checkpoints; nbr (k^3, n) tap-major.
-    compute_dtype: torch.bfloat16 -> fused MFMA kernels on bf16 operands; "bf16x3" -> the same kernels on hi/lo-split
-    operands (near-fp32 result, the reference's precision for this op); torch.float32 -> per-tap gather + fp32 GEMM."""
+    compute_dtype: torch.bfloat16 -> fused MFMA kernels on bf16 operands; "bf16x3" -> the reference's fp32 precision for this op on the
+    matrix cores: exact fp32 MFMA for the 32-channel stage (walk_fn: the level's cached walk-order rulebook), else the bf16
+    kernels on hi/lo-split operands; torch.float32 -> per-tap gather + fp32 GEMM."""
     if compute_dtype == torch.bfloat16 and weight.shape[0] % 8 == 0:
         return _SubMConv3dFused.apply(feat, weight, bias, nbr, rowperm, blocks_fn, has_dup)
     if compute_dtype == "bf16x3":
+        if (CONV_F32_MFMA and weight.shape[0] == 32 and weight.shape[-1] <= 32 and not has_dup and feat.is_cuda
+                and (weight.shape[-1] == 32 or not feat.requires_grad)):
+            return _SubMConv3dF32.apply(feat, weight, bias, nbr, rowperm, blocks_fn, walk_fn)
         if weight.shape[0] % 8 == 0 and not has_dup and feat.is_cuda:
             return _SubMConv3dSplit.apply(feat, weight, bias, nbr, rowperm, blocks_fn)
         compute_dtype = torch.float32            # duplicate voxels (Mix3D) / odd widths: the per-tap fp32 path

@@ -334,6 +334,57 @@ def subm_conv_wgrad(x, dout, nbr, rowperm, blocks, out=None):
     return dw
 
 
+def subm_f32_weight_layout(w, mirror=False):
+    """w (32, taps, c) f32 -> the fp32-MFMA conv's operand layout [tap][cp / 8][2][32][4] (cp = c padded to 16 or 32).
+    mirror: the dgrad operand, w'[ci][T-1-t][co] = w[co][t][ci] (needs c == 32)."""
+    w = w.float()
+    if mirror:
+        w = w.flip(1).permute(2, 1, 0)
+    co, taps, c = w.shape
+    cp = 16 if c <= 16 else 32
+    if co != 32 or c > 32:
+        raise RuntimeError("subm_f32: 32 output channels, at most 32 input channels")
+    if cp != c:
+        w = torch.nn.functional.pad(w, (0, cp - c))
+    return w.reshape(32, taps, cp // 8, 2, 4).permute(1, 2, 3, 0, 4).contiguous()
+
+
+def subm_walk_rulebook(nbr, rowperm):
+    """The rulebook in walk order: (taps, n) with [t][k] = nbr[t][rowperm[k]] (rowperm None: nbr itself)."""
+    return nbr if rowperm is None else nbr.index_select(1, rowperm).contiguous()
+
+
+def subm_f32_fwd(x, wq, bias, nbr, rowperm):
+    """x (n, cp) f32 (cp 16 | 32), wq from subm_f32_weight_layout, nbr = subm_walk_rulebook(...) -> (n, 32) f32, exact fp32
+    products (v_mfma_f32_32x32x2_f32)."""
+    n, cp = x.shape
+    taps = nbr.shape[0]
+    _req(x, torch.float32, "x"); _req(wq, torch.float32, "wq", (taps, cp // 8, 2, 32, 4)); _req(nbr, torch.int32, "nbr", (taps, n))
+    if bias is not None:
+        _req(bias, torch.float32, "bias", (32,))
+    if rowperm is not None:
+        _req(rowperm, torch.int32, "rowperm", (n,))
+    out = torch.empty((n, 32), dtype=torch.float32, device=x.device)
+    check(lib().ss_subm_f32_fwd(_p(x), _p(wq), _p(bias), _p(nbr), _p(rowperm), _p(out), n, cp, 32, taps, _stream()), "ss_subm_f32_fwd")
+    return out
+
+
+def subm_f32_wgrad(x, dout, nbr, rowperm, blocks, cin):
+    """-> dW (32, taps, cin) f32 = sum_i dout[i] (x) x[nbr[t][i]][:cin]; x (n, cp) f32, dout (n, 32) f32; nbr in walk order
+    (subm_walk_rulebook), blocks = subm_block_lists(original nbr, rowperm)."""
+    n, cp = x.shape
+    taps = nbr.shape[0]
+    _req(x, torch.float32, "x"); _req(dout, torch.float32, "dout", (n, 32)); _req(nbr, torch.int32, "nbr", (taps, n))
+    if rowperm is not None:
+        _req(rowperm, torch.int32, "rowperm", (n,))
+    cnt, lst = blocks
+    _req(cnt, torch.int32, "blk_count", (taps,)); _req(lst, torch.int32, "blk_list", (taps, (n + 63) // 64))
+    dw = zeros_f32(32 * taps * cin, x.device).view(32, taps, cin)
+    check(lib().ss_subm_f32_wgrad(_p(x), _p(dout), _p(nbr), _p(rowperm), _p(cnt), _p(lst), _p(dw), n, cp, cin, 32, taps, _stream()),
+          "ss_subm_f32_wgrad")
+    return dw
+
+
 def subm_conv_wgrad_pipe(x, dout, nbr, rowperm, blocks):
     """The pipeline weight-gradient kernel directly (tests / benches)."""
     n, cin = x.shape

@@ -136,6 +136,16 @@ class Level:
             self._nbr[key] = b
         return b
 
+    def neighbors_walk(self, ksize):
+        """The rulebook in conv_rowperm order, [t][k] = neighbors(ksize)[t][rowperm[k]]: what the fp32-MFMA first-stage conv reads
+        (csrc/subm_f32.hip) -- 128 contiguous bytes per tap and 32-site tile instead of 32 scattered words."""
+        key = ("walk", ksize)
+        w = self._nbr.get(key)
+        if w is None:
+            w = nv.subm_walk_rulebook(self.neighbors(ksize), self.conv_rowperm())
+            self._nbr[key] = w
+        return w
+
     def neighbors(self, ksize):
         """(k^3, n) int32 tap-major rulebook, shared by every conv of this level (indice_key)."""
         nb = self._nbr.get(ksize)
@@ -247,11 +257,13 @@ class ScenePlan:
 
     def materialize(self, window_specs=(), kernel_sizes=()):
         """Build the lazily cached pieces now (on the current stream): window_specs = [(level, curve index,
-        patch)], kernel_sizes = [(level, k)]."""
+        patch)], kernel_sizes = [(level, k) | (level, k, True: also the walk-order rulebook)]."""
         for li, j, patch in window_specs:
             self.levels[li].window(j, patch)
-        for li, k in kernel_sizes:
+        for li, k, *walk in kernel_sizes:
             self.levels[li].neighbors(k); self.levels[li].conv_blocks(k)
+            if walk and walk[0]:
+                self.levels[li].neighbors_walk(k)
 
     def record_stream(self, stream):
         """The plan was allocated on another stream: keep the caching allocator from reusing its memory

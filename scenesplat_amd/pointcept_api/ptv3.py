@@ -89,7 +89,7 @@ class SubMConv3d(nn.Module):
         cd = conv_dtype_for(self.weight.shape[0])
         return SF.subm_conv3d(feat, self.weight, self.bias, level.neighbors(self.kernel_size),
                               level.has_duplicates, cd, level.conv_rowperm(),
-                              lambda: level.conv_blocks(self.kernel_size))
+                              lambda: level.conv_blocks(self.kernel_size), lambda: level.neighbors_walk(self.kernel_size))
 
 
 def _lin(mod, x):
@@ -305,6 +305,7 @@ class PointTransformerV3(PointModule):
             return nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)
 
         ln_layer, act_layer = nn.LayerNorm, nn.GELU
+        self.enc_channels = tuple(enc_channels)
         self.embedding = Embedding(in_channels, enc_channels[0], bn_layer, act_layer)
         blk = dict(mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=proj_drop,
                    norm_layer=ln_layer, act_layer=act_layer, pre_norm=pre_norm, enable_rpe=enable_rpe,
@@ -349,10 +350,12 @@ class PointTransformerV3(PointModule):
     def plan_specs(self):
         """Everything the float pipeline will ask the plan for: (window specs, conv kernel sizes)."""
         K = len(self.order)
-        wins, ks = [], [(0, 5)]
+        # 32-channel convs at the reference's fp32 precision run on the fp32-MFMA kernels, which read the rulebook in walk order
+        walk = [SF.CONV_F32_MFMA and c == 32 and conv_dtype_for(c) == "bf16x3" for c in self.enc_channels]
+        wins, ks = [], [(0, 5, walk[0])]
         for s in range(self.num_stages):
             enc = getattr(self.enc, f"enc{s}")
-            ks.append((s, 3))
+            ks.append((s, 3, walk[s]))
             for i in range(self.enc_depths[s]):
                 wins.append((s, i % K, getattr(enc, f"block{i}").attn.patch_size))
         if not self.cls_mode:

@@ -50,6 +50,8 @@ def setter(on):
         RUNTIME["attn_headmajor"] = on
     elif which == "group_cast":
         SF.SHADOW_GROUP_CAST = on
+    elif which == "conv_f32":
+        SF.CONV_F32_MFMA = on
     elif which == "mask_small":
         import scenesplat_amd.plan as P
         P.CONV_MASK_MIN_SITES = 4096 if on else 16384
