@@ -91,6 +91,8 @@ int ss_cast_bf16_group_elems_per_workgroup(void);
 /* ---- runtime queries -------------------------------------------------------------------- */
 /* 0 = the stream is not capturing, 1 = capturing, 2 = its capture was invalidated (abandon it: never end it), < 0 = query failed */
 int ss_stream_capture_status(ss_stream_t stream);
+/* identity (> 0) of the capture the stream is actively recording into, 0 = none / unknown */
+unsigned long long ss_stream_capture_id(ss_stream_t stream);
 
 /* ---- head-major window attention (round 3) ------------------------------------------------------------
  * hm (sections = 3, num_heads, n_pad, head_dim) bf16: q / k / v of padded slot p of the curve order (slot p = point gidx[p]);

@@ -37,6 +37,7 @@ PROTOTYPES = {
     "ss_window_attn_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i, c_f, c_i, c_i,
                                  c_p, c_p, c_sz, c_p]),
     "ss_stream_capture_status": (c_i, [c_p]),
+    "ss_stream_capture_id": (ctypes.c_ulonglong, [c_p]),
     "ss_cast_bf16_group": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "ss_cast_bf16_group_elems_per_workgroup": (c_i, []),
     "ss_linear_fwd_headmajor": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_f, c_p]),

@@ -420,6 +420,16 @@ def _stamp(p):
     return (p._version, p.data_ptr())
 
 
+def _shadow_current(ent, p):
+    """Is the shadow entry current: written eagerly for this parameter version, or recorded inside the capture now running."""
+    tag = ent[1]
+    if tag is None:
+        return False
+    if tag[0] == "capture":
+        return tag[1] != 0 and torch.cuda.is_current_stream_capturing() and tag[1] == nv.stream_capture_id()
+    return tag == _stamp(p)
+
+
 def register_shadows(params):
     """-> (sources, shadows) lists for refresh_shadows; idempotent per parameter."""
     src, dst = [], []
@@ -445,22 +455,28 @@ def refresh_shadows(src, dst):
     # inside a hipGraph capture every shadow is re-cast: the replayed step must pick up whatever the optimizer wrote
     # since the previous replay, and a copy skipped now would be missing from the graph for good
     everything = torch.cuda.is_current_stream_capturing()
+    cap = ("capture", nv.stream_capture_id()) if everything else None
     for p, d in zip(src, dst):
         ent = _SHADOW.get(p)
         st = _stamp(p)
         if everything or ent is None or ent[0] is not d or ent[1] != st:
             todo_s.append(p); todo_d.append(d)
             if ent is not None and ent[0] is d:
-                # while capturing the copy is only RECORDED (it runs at replay): leave the shadow marked stale, so that an
-                # eager step after a refused capture re-casts instead of trusting weights one optimizer step old
-                ent[1] = None if everything else st
+                # while capturing the copy is only RECORDED (it runs at replay): the shadow is current for THIS capture only
+                # (bf16_of / mirrored_of / transposed_of compare the capture's identity) and stale for everything else, so
+                # that an eager step after a refused capture re-casts instead of trusting weights one optimizer step old
+                ent[1] = cap if everything else st
     if todo_s:
         # one launch for all of them (torch._foreach_copy_ with a dtype change is one copy kernel PER TENSOR: 206 launches and
         # 1.2 ms per step on the lang-pretrain model); anything that is not a contiguous fp32 -> bf16 pair takes the torch path
         fast = [(s_, d_) for s_, d_ in zip(todo_s, todo_d) if s_.is_cuda and s_.dtype == torch.float32 and d_.dtype == torch.bfloat16
                 and s_.is_contiguous() and d_.is_contiguous() and s_.numel() == d_.numel()]
-        if SHADOW_GROUP_CAST and len(fast) == len(todo_s):
+        if SHADOW_GROUP_CAST and fast:
             nv.cast_bf16_group([a for a, _ in fast], [b for _, b in fast])
+            if len(fast) != len(todo_s):
+                done = {id(d_) for _, d_ in fast}
+                rest = [(s_, d_) for s_, d_ in zip(todo_s, todo_d) if id(d_) not in done]
+                torch._foreach_copy_([d_ for _, d_ in rest], [s_ for s_, _ in rest])
         else:
             torch._foreach_copy_(todo_d, todo_s)
         pairs = [(d, _SHADOW_T[p]) for p, d in zip(todo_s, todo_d) if p in _SHADOW_T]
@@ -495,7 +511,7 @@ def mirrored_of(p):
     if m is None:
         return None
     ent = _SHADOW.get(p)
-    return m if (ent is not None and ent[1] == _stamp(p)) else None
+    return m if (ent is not None and _shadow_current(ent, p)) else None
 
 
 def register_transposed(weights):
@@ -520,7 +536,7 @@ def bf16_t_of(p):
     if t is None:
         return None
     ent = _SHADOW.get(p)
-    return t if (ent is not None and ent[1] == _stamp(p)) else None
+    return t if (ent is not None and _shadow_current(ent, p)) else None
 
 
 def bf16_of(p):
@@ -530,7 +546,7 @@ def bf16_of(p):
     if p.dtype == torch.bfloat16:
         return p
     ent = _SHADOW.get(p) if isinstance(p, torch.nn.Parameter) else None
-    if ent is not None and ent[1] == _stamp(p):
+    if ent is not None and _shadow_current(ent, p):
         return ent[0]
     return p.to(torch.bfloat16)
 

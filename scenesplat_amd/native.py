@@ -904,6 +904,12 @@ def stream_capture_status(stream=None):
     return int(lib().ss_stream_capture_status(ctypes.c_void_p(st.cuda_stream)))
 
 
+def stream_capture_id(stream=None):
+    """> 0: identity of the capture the stream is recording into; 0: not capturing."""
+    st = stream if stream is not None else torch.cuda.current_stream()
+    return int(lib().ss_stream_capture_id(ctypes.c_void_p(st.cuda_stream)))
+
+
 def cast_bf16_group(srcs, dsts):
     """ONE launch: dst (bf16) = src (fp32) for every pair of equally shaped contiguous tensors (the weight shadows)."""
     import numpy as np

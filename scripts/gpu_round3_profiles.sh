@@ -24,7 +24,7 @@ for r in rows[:45]:
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(trace)):
     k = r["Kernel_Name"].split("(")[0]
-    if any(t in k for t in ("k_gemm8", "k_wgrad8", "k_attn", "k_gather_add", "k_segment_reduce", "k_segment_bcast", "k_hm_pack", "k_feat_text_scan", "k_gather_rows")):
+    if any(t in k for t in ("k_gemm8", "k_wgrad8", "k_attn", "k_gather_add", "k_segment_reduce", "k_segment_bcast", "k_hm_pack", "k_feat_text_scan", "k_gather_rows", "k_subm_f32")):
         acc[(k[:64], r["Grid_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 out += ["", "## Roofline kernels in this trace, per launch shape", "", "| kernel | grid (threads) | launches | mean us (min, max) |", "|---|---|---|---|"]
 for (k, g), v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:36]:

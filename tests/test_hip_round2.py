@@ -202,6 +202,39 @@ def test_bf16_shadows_follow_the_parameters():
             assert torch.equal(a, b), (shadows, (a - b).abs().max())
 
 
+def test_shadows_recorded_inside_a_capture_serve_that_capture_and_nothing_else(monkeypatch):
+    """refresh_shadows inside a hipGraph capture only RECORDS the casts: the shadows must serve the layers of that capture (no
+    per-use re-cast kernels in the graph -- 188 small copies and 1.1 ms per replayed step when this was wrong), and must read as
+    stale to eager code afterwards (a refused capture leaves weights one optimizer step old in them)."""
+    from scenesplat_amd import functional as SF, native as nv
+    # the multi-tensor copy is capturable as it stands; the one-launch group cast uploads its descriptor table through the
+    # steady-state capture pool (steady_state.py), which this bare capture does not set up
+    monkeypatch.setattr(SF, "SHADOW_GROUP_CAST", False)
+    lin = torch.nn.Linear(64, 64).cuda()
+    src, dst = SF.register_shadows([lin.weight, lin.bias])
+    SF.refresh_shadows(src, dst)
+    assert SF.bf16_of(lin.weight) is dst[0] and nv.stream_capture_id() == 0
+    with torch.no_grad():
+        lin.weight.add_(1.0)
+    assert SF.bf16_of(lin.weight) is not dst[0]                       # stale after an in-place update
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        graph.capture_begin(capture_error_mode="thread_local")
+        ids = nv.stream_capture_id()
+        SF.refresh_shadows(src, dst)
+        inside = (SF.bf16_of(lin.weight) is dst[0], SF.bf16_of(lin.bias) is dst[1])
+        graph.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    assert ids > 0 and inside == (True, True)
+    assert SF.bf16_of(lin.weight) is not dst[0]                       # recorded, not run: stale for eager code
+    graph.replay(); torch.cuda.synchronize()
+    assert torch.equal(dst[0], lin.weight.detach().to(torch.bfloat16))
+    SF.refresh_shadows(src, dst)                                      # eager refresh makes them current again
+    assert SF.bf16_of(lin.weight) is dst[0]
+
+
 # ---- BASELINE config 3 -------------------------------------------------------------------------------------------
 def test_config3_lang_pretrainer_b8_x_102400_one_step():
     """ScanNet vision-language pretrain shape: LangPretrainer (PT-v3m1 lang config + 3 criteria), batch = 8 chunks of
