@@ -88,6 +88,11 @@ int ss_window_attn_bwd(const void* qkv, const void* out, const void* dout, const
 int ss_cast_bf16_group(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups, ss_stream_t stream);
 int ss_cast_bf16_group_elems_per_workgroup(void);
 
+/* ---- DropPath row scales (timm DropPath on (n, C) rows, ptv3:333-336) ------------------------------------
+ * out[i] = Bernoulli(keep[i]) / keep[i] for the n rows of all residual seams of a forward; Philox4x32-10, counter = row index,
+ * key = the 64-bit seed read from DEVICE memory (so a captured launch draws fresh masks per replay). */
+int ss_row_keep_scales(const int64_t* seed, const float* keep, float* out, int64_t n, ss_stream_t stream);
+
 /* ---- runtime queries -------------------------------------------------------------------- */
 /* 0 = the stream is not capturing, 1 = capturing, 2 = its capture was invalidated (abandon it: never end it), < 0 = query failed */
 int ss_stream_capture_status(ss_stream_t stream);

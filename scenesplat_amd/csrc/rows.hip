@@ -451,6 +451,47 @@ extern "C" int ss_cast_bf16_group(const int64_t* desc, const int32_t* wg_start, 
   return SS_OK;
 }
 
+// ---- DropPath row scales of ALL residual seams of a forward in one launch ------------------------------------------------------
+// timm DropPath on (n, C) rows (ptv3:333-336): scale[i] = Bernoulli(keep[i]) / keep[i], one draw per row and seam.  The uniform
+// draws come from Philox4x32-10 keyed by a 64-bit seed that lives in DEVICE memory (drawn by torch's generator: graph-safe, fresh per
+// replay) with the row index as the counter -- torch.rand over the 1.09 M rows of the lang-pretrain model cost 0.21 ms per step
+// plus two elementwise launches; this is one ~4 us launch.  Not torch's random stream: the reference's masks are not reproducible
+// across libraries either (parity fixtures run with drop_path = 0).
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_row_keep_scales(const int64_t* __restrict__ seed, const float* __restrict__ keep, float* __restrict__ out, int64_t n) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;           // four consecutive rows per thread
+  if (q * 4 >= n) return;
+  const uint64_t sd = (uint64_t)seed[0];
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), 0u, 0u};
+  philox4x32_10(c, (uint32_t)sd, (uint32_t)(sd >> 32));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t i = q * 4 + j;
+    if (i < n) {
+      const float k = keep[i], u = (float)(c[j] >> 8) * (1.0f / 16777216.0f);
+      out[i] = u < k ? 1.0f / k : 0.0f;
+    }
+  }
+}
+
+extern "C" int ss_row_keep_scales(const int64_t* seed, const float* keep, float* out, int64_t n, hipStream_t stream) {
+  if (n < 0 || (n > 0 && (!seed || !keep || !out))) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  SS_LAUNCH(k_row_keep_scales, dim3((unsigned)ss_div_up(ss_div_up(n, 4), 256)), dim3(256), 0, stream, seed, keep, out, n);
+  return SS_OK;
+}
+
 // ---- grouped form of k_subm_weight_mirror: the dgrad weights of ALL convs of a model in one launch (refreshed with the bf16 shadows) ----
 // desc: 5 int64 words per problem = {w, wt, cout, taps, cin}; wg_start (nprob + 1); a workgroup owns one (tap, 32 x 32) tile.
 __global__ void __launch_bounds__(256)

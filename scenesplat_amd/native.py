@@ -904,6 +904,18 @@ def stream_capture_status(stream=None):
     return int(lib().ss_stream_capture_status(ctypes.c_void_p(st.cuda_stream)))
 
 
+def row_keep_scales(keep, seed=None):
+    """keep (n) f32 in (0, 1] -> (n) f32 of Bernoulli(keep) / keep, one Philox draw per row.  seed: (1,) int64 DEVICE tensor; None draws
+    it from torch's generator of the device (graph-safe: a captured call gets a fresh seed on every replay)."""
+    _req(keep, torch.float32, "keep")
+    if seed is None:
+        seed = torch.randint(-(1 << 62), 1 << 62, (1,), dtype=torch.int64, device=keep.device)
+    _req(seed, torch.int64, "seed", (1,))
+    out = torch.empty_like(keep)
+    check(lib().ss_row_keep_scales(_p(seed), _p(keep), _p(out), keep.numel(), _stream()), "ss_row_keep_scales")
+    return out
+
+
 def stream_capture_id(stream=None):
     """> 0: identity of the capture the stream is recording into; 0: not capturing."""
     st = stream if stream is not None else torch.cuda.current_stream()

@@ -425,7 +425,7 @@ class PointTransformerV3(PointModule):
 
     def _draw_row_scales(self, levels, device):
         """DropPath masks (one Bernoulli(keep)/keep scale per row and residual seam, timm DropPath on (n,C) rows as
-        ptv3:333-336) of ALL blocks from one uniform draw: 3 launches per forward instead of 2 per seam (88)."""
+        ptv3:333-336) of ALL blocks from one launch (plus the seed draw) per forward instead of 2 per seam (88)."""
         blocks = []
         for s in range(self.num_stages):
             enc = getattr(self.enc, f"enc{s}")
@@ -449,7 +449,7 @@ class PointTransformerV3(PointModule):
             cache = (key, kv)
             self.__dict__["_keep_vec"] = cache
         kv = cache[1]
-        scales = (torch.rand(kv.shape[0], device=device) < kv).to(torch.float32).div_(kv)
+        scales = nv.row_keep_scales(kv)          # Bernoulli(keep) / keep per row: one Philox launch (csrc/rows.hip)
         off = 0
         for blk, n, _ in segs:
             blk.__dict__["_row_scales"].append(scales[off:off + n])

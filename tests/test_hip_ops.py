@@ -572,3 +572,28 @@ def test_rulebook_hashed_equals_sorted_lookup(k, dup, monkeypatch):
     assert torch.equal(tabs[0], tabs[1])
     batch = np.repeat([0, 1], [n // 3, n - n // 3])
     assert np.array_equal(tabs[1].numpy(), np.asarray(oops.neighbor_table(gc.numpy(), batch, k)).T)
+
+
+def test_row_keep_scales_are_bernoulli_over_keep_and_follow_the_seed():
+    """DropPath row scales (timm DropPath on (n, C) rows, ptv3:333-336): values in {0, 1/keep}, keep rate within 5 sigma per
+    segment, same seed -> same masks, other seed -> other masks, neighbouring rows uncorrelated."""
+    from scenesplat_amd import native as nv
+    n = 400_003
+    keep = torch.cat([torch.full((n // 2,), 0.9), torch.full((n - n // 2,), 0.7)]).cuda()
+    s0 = torch.tensor([1234567], dtype=torch.int64, device="cuda")
+    a = nv.row_keep_scales(keep, s0); b = nv.row_keep_scales(keep, s0)
+    c = nv.row_keep_scales(keep, torch.tensor([7654321], dtype=torch.int64, device="cuda"))
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    on = a > 0
+    assert torch.allclose(a[on], (1.0 / keep)[on])
+    for sl, k in ((slice(0, n // 2), 0.9), (slice(n // 2, n), 0.7)):
+        m = sl.stop - sl.start
+        rate = float(on[sl].float().mean())
+        assert abs(rate - k) < 5 * (k * (1 - k) / m) ** 0.5, (rate, k)
+    x = on[: n // 2].float() - 0.9
+    corr = float((x[1:] * x[:-1]).mean() / (0.9 * 0.1))
+    assert abs(corr) < 0.02, corr
+    d = nv.row_keep_scales(keep)                       # seed from torch's generator: differs call to call
+    e = nv.row_keep_scales(keep)
+    assert not torch.equal(d, e)
+    assert nv.row_keep_scales(keep[:0]).numel() == 0
