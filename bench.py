@@ -395,7 +395,12 @@ def main():
     # a side stream while step k's backward runs, the way a data-loader prefetch would: its few
     # device->host round trips then never drain the float pipeline.  Every step still builds its own plan.
     side = torch.cuda.Stream()
-    state = {"plan": model.prepare_plan(data, stream=side)}
+    # SS_BENCH_PLAN_AHEAD=0 is a DIAGNOSTIC: build each plan between two steps on the step loop's own thread (round 2's form)
+    plan_ahead = None
+    if os.environ.get("SS_BENCH_PLAN_AHEAD", "1") != "0" and os.environ.get("SS_BENCH_REUSE_PLAN") != "1":
+        from scenesplat_amd.plan import PlanAhead
+        plan_ahead = PlanAhead(lambda: model.prepare_plan(data, stream=side), depth=2)
+    state = {"plan": plan_ahead.get() if plan_ahead is not None else model.prepare_plan(data, stream=side)}
 
     cot16 = cot.to(torch.bfloat16)
 
@@ -442,7 +447,10 @@ def main():
         t_d = time.perf_counter()
         # SS_BENCH_REUSE_PLAN=1 is a DIAGNOSTIC (host- vs GPU-bound?): it skips the per-step plan build and the line it
         # prints is not the metric
-        state["plan"] = plan if os.environ.get("SS_BENCH_REUSE_PLAN") == "1" else model.prepare_plan(data, stream=side)
+        if plan_ahead is not None:
+            state["plan"] = plan_ahead.get()       # built by the plan thread while earlier steps ran (scenesplat_amd/plan.py:PlanAhead)
+        else:
+            state["plan"] = plan if os.environ.get("SS_BENCH_REUSE_PLAN") == "1" else model.prepare_plan(data, stream=side)
         if seg is not None:      # DIAGNOSTIC: where the host spends a step (ms, summed over all steps incl. warm-up)
             seg["zero"] += t_b - t_a; seg["steady"] += t_c - t_b; seg["reduce"] += t_d - t_c; seg["plan"] += time.perf_counter() - t_d
 
@@ -492,6 +500,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if plan_ahead is not None:
+        plan_ahead.close()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -514,7 +524,7 @@ def main():
                                     "1 chunk of %d Gaussians per GPU per step, serialization included") % (n, n),
                        "gaussians_per_chunk": n, "chunks_per_gpu": 1,
                        "parallelism": "dp%d" % world, "gradient_exchange": (args.exchange if (world > 1 or force_ddp) else "none"), "attention_kernel": "mfma" if impl == nv.ATTN_MFMA else "simt",
-                       "execution": ("hipGraph replay of forward+backward (%d of the %d timed steps; plan rebuilt and copied in every step)"
+                       "execution": ("hipGraph replay of forward+backward (%d of the %d timed steps; a plan built for every step, by the plan thread, and copied in)"
                                      % (steady.replays - replays_before, args.steps)) if steady.replays > replays_before else "eager launches"},
         }
         log("timed %d steps: %.1f ms/step (host enqueue %.1f ms/step)" % (args.steps, dt / args.steps * 1e3, t_enq / args.steps * 1e3))

@@ -338,3 +338,62 @@ def build_plan(grid_coord, offset, order_names, strides, perms=None, depth=None)
     if len(strides) == 0:
         levels[0].has_duplicates = int(dup.item()) > 0
     return ScenePlan(levels, list(order_names))
+
+
+class PlanAhead:
+    """Integer plans built by a HOST THREAD, `depth` steps ahead of the float pipeline.
+
+    A plan build has host round trips (depth, pooled sizes: structure.py:69-74, ptv3:392-400 need them on the host to size
+    tensors).  Its small kernels share the GPU with a step that fills every CU, so they are often scheduled only when the
+    running step thins out at its end -- and a loop that builds the next plan between two steps then blocks until the
+    current step is over, enqueues the next one late and leaves the GPU idle for the host's latency (1.0-1.5 ms per 39 ms
+    step measured on the replayed bench step, 2.5 ms in a cold process: scripts/trace_step.sh).  With the builds on their
+    own thread (and their own stream) the step loop never waits: it takes a finished plan and enqueues.  The role of a
+    data-loader worker; the reference does the same work inside the model's forward (structure.py:47-102).
+
+        ahead = PlanAhead(lambda: model.prepare_plan(next_batch(), stream=side), depth=2)
+        plan = ahead.get()            # every step
+        ahead.close()
+    """
+
+    def __init__(self, build, depth=2, device=None):
+        import queue
+        import threading
+        self._build, self._q, self._stop, self._err = build, queue.Queue(maxsize=max(1, int(depth))), False, None
+        self._device = torch.cuda.current_device() if device is None and torch.cuda.is_available() else device
+        self._t = threading.Thread(target=self._run, name="ss-plan-ahead", daemon=True)
+        self._t.start()
+
+    def _run(self):
+        import queue
+        try:
+            if self._device is not None:
+                torch.cuda.set_device(self._device)
+            while not self._stop:
+                plan = self._build()
+                while not self._stop:
+                    try:
+                        self._q.put(plan, timeout=0.05)
+                        break
+                    except queue.Full:
+                        pass
+        except BaseException as e:  # noqa: BLE001 -- handed to the consumer
+            self._err = e
+            self._q.put(None)
+
+    def get(self):
+        plan = self._q.get()
+        if plan is None:
+            self._stop = True
+            raise RuntimeError("plan build thread failed") from self._err
+        return plan
+
+    def close(self):
+        import queue
+        self._stop = True
+        try:
+            while True:
+                self._q.get_nowait()
+        except queue.Empty:
+            pass
+        self._t.join(timeout=30)

@@ -235,6 +235,43 @@ def test_shadows_recorded_inside_a_capture_serve_that_capture_and_nothing_else(m
     assert SF.bf16_of(lin.weight) is dst[0]
 
 
+def test_plan_ahead_thread_hands_over_plans_equal_to_direct_builds():
+    """PlanAhead (scenesplat_amd/plan.py): plans built on a host thread and a side stream, consumed by the step loop: same
+    signature and tensors as a direct build, usable by the model, failures surface in get(), close() ends the thread."""
+    from scenesplat_amd.plan import PlanAhead
+    from scenesplat_amd.pointcept_api import MODELS
+    d = _tiny_input(32, 1)
+    inp = dict(feat=d["feat"], grid_coord=d["grid_coord"], offset=d["offset"])
+    with _Runtime(conv_dtype=torch.float32, attn_impl=0, param_shadows=False):
+        torch.manual_seed(0)
+        model = MODELS.build(dict(type="PT-v3m1", **TINY, drop_path=0.0, shuffle_orders=False)).cuda().eval()
+        side = torch.cuda.Stream()
+        perms = model.draw_perms()            # pooled levels shuffle their curve order per plan (ptv3:371-444): pin it
+        ahead = PlanAhead(lambda: model.prepare_plan(inp, perms=perms, stream=side), depth=2)
+        direct = model.prepare_plan(inp, perms=perms)
+        with torch.no_grad():
+            ref = model(dict(inp, plan=direct)).feat
+            for _ in range(3):
+                plan = ahead.get()
+                assert plan.signature() == direct.signature()
+                torch.cuda.current_stream().wait_event(plan.ready_event)
+                for (ra, ta), (rb, tb) in zip(plan._slots(), direct._slots()):
+                    assert ra == rb and ta.shape == tb.shape
+                    if ra[1] in ("codes", "order", "inverse", "grid_coord", "batch"):      # (others carry unwritten tails)
+                        assert torch.equal(ta, tb), ra
+                out = model(dict(inp, plan=plan)).feat
+                assert torch.equal(out, ref)
+        ahead.close()
+        assert not ahead._t.is_alive()
+
+        def boom():
+            raise ValueError("no batch")
+        bad = PlanAhead(boom, depth=1)
+        with pytest.raises(RuntimeError, match="plan build thread failed"):
+            bad.get()
+        bad.close()
+
+
 # ---- BASELINE config 3 -------------------------------------------------------------------------------------------
 def test_config3_lang_pretrainer_b8_x_102400_one_step():
     """ScanNet vision-language pretrain shape: LangPretrainer (PT-v3m1 lang config + 3 criteria), batch = 8 chunks of
