@@ -19,7 +19,8 @@ copies; no host callback per parameter beyond a counter.
 
 hooks=False ("packed" mode, for steps replayed as a hipGraph -- steady_state.py -- where no host callback can run inside the
 backward): the step itself ends with ex.pack() (one multi-tensor copy per stage, captured with the step), and after the replay
-ex.reduce() issues the stage all-reduces and finishes.  Nothing overlaps the backward then (about 2-3 ms of exposed all-reduce at
+ex.reduce() issues ONE all-reduce over the whole model (the stage buffers are consecutive slices of one allocation; ReduceOp.AVG where
+the backend has it) and finishes.  Nothing overlaps the backward then (about 2-3 ms of exposed all-reduce at
 8 ranks for the 367 MB of this model), but the host enqueues ~170 calls per step instead of ~1,300: measured on one rank, the
 eager step under either DDP or the hook form is HOST-bound (44-47 ms/step of enqueue against 39 ms of GPU work), so the packed form
 is what bench.py uses for N > 1.
@@ -53,6 +54,8 @@ class StageGradExchange:
         self.prof = {"hooks": 0, "launch_s": 0.0, "finish_s": 0.0, "steps": 0} if os.environ.get("SS_EXCHANGE_PROFILE") else None
         self._order = []
         self._hooks = []
+        self._avg_ok = None           # does the backend implement ReduceOp.AVG?  (probed by the first packed reduce)
+        self.whole = {}
         self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())     # force: one-rank rehearsal
         if not self.active:
             return
@@ -61,6 +64,7 @@ class StageGradExchange:
                 continue
             st = self.stages.setdefault(stage_of(name), dict(params=[], names=[]))
             st["params"].append(p); st["names"].append(name)
+        plans = {}
         for label, st in self.stages.items():
             dev, dt = st["params"][0].device, st["params"][0].dtype
             if any(p.device != dev or p.dtype != dt for p in st["params"]):
@@ -69,7 +73,18 @@ class StageGradExchange:
             for p in st["params"]:
                 offs.append(tot)
                 tot += (p.numel() + 63) // 64 * 64          # slots start on 256-byte boundaries
-            st["flat"] = torch.zeros(tot, dtype=dt, device=dev)
+            plans[label] = (dev, dt, offs, tot)
+        # the stage buffers are consecutive slices of ONE allocation per (device, dtype): the packed form reduces the whole model
+        # with one collective, the hook form one slice per stage
+        self.whole = {}
+        for label, (dev, dt, offs, tot) in plans.items():
+            self.whole.setdefault((dev, dt), [0, None])[0] += tot
+        for key, ent in self.whole.items():
+            ent[1] = torch.zeros(ent[0], dtype=key[1], device=key[0]); ent[0] = 0
+        for label, st in self.stages.items():
+            dev, dt, offs, tot = plans[label]
+            ent = self.whole[(dev, dt)]
+            st["flat"] = ent[1][ent[0]:ent[0] + tot]; ent[0] += tot
             st["views"] = [st["flat"][o:o + p.numel()].view_as(p) for o, p in zip(offs, st["params"])]
             st["count"], st["handle"] = 0, None
             if hooks:
@@ -117,15 +132,30 @@ class StageGradExchange:
         # stream-synchronous collectives (async_op=False): with RCCL the call returns once the all-reduce is enqueued and the compute
         # stream is made to wait for it -- nothing overlaps here anyway, and no Work handle has to be waited for on the host
         t0 = time.perf_counter()
+        for ent in self.whole.values():
+            self._reduce_whole(ent[1])
         for st in self.stages.values():
-            dist.all_reduce(st["flat"], op=dist.ReduceOp.SUM, group=self.group)
-            if self.average and self.world > 1:
-                st["flat"].div_(self.world)
             for p, v in zip(st["params"], st["views"]):
                 p.grad = v
             st["count"], st["handle"] = 0, None
         if self.prof is not None:
             self.prof["finish_s"] += time.perf_counter() - t0; self.prof["steps"] += 1
+
+    def _reduce_whole(self, buf):
+        """One collective over every stage buffer of a (device, dtype): the mean when the backend has it (RCCL: ReduceOp.AVG, no
+        extra pass over the 367 MB), else sum + one division (gloo)."""
+        if self.average and self.world > 1 and self._avg_ok is not False:
+            try:
+                dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group)
+                self._avg_ok = True
+                return
+            except (RuntimeError, ValueError, NotImplementedError):
+                if self._avg_ok:            # it worked before: a real failure, not a missing feature
+                    raise
+                self._avg_ok = False
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        if self.average and self.world > 1:
+            buf.div_(self.world)
 
     def finish(self):
         """Call after backward(): launches the stages whose count never completed (parameters without a gradient this step), waits
