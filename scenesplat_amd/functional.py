@@ -565,13 +565,26 @@ WGRAD_GROUP_MAX_ROWS = int(os.environ.get("SS_WGRAD_GROUP_MAX", str(1 << 22)))  
 _STAGE = {"cur": None, "route": {}}
 
 
+# queued (x, dy) operands of a stage stay alive until its group is launched: 3 GB at dec0 for one 102,400-row chunk, 8x that for the
+# B = 8 step of config 3.  Above this many queued bytes the stage launches what it holds (a smaller group) and goes on queueing.
+WGRAD_GROUP_MAX_BYTES = int(float(os.environ.get("SS_WGRAD_GROUP_MAX_GIB", "8")) * (1 << 30))
+
+
 class _WgradStage:
     def __init__(self):
         self.queue = []          # (x, dy, dW, db): nn.Linear weight gradients
         self.redq = []           # (part (K, nb, C), dst (K, C)): LayerNorm dgamma / dbeta partial sums
+        self.bytes = 0
+
+    def add(self, x, dy, dw, db):
+        self.queue.append((x, dy, dw, db))
+        self.bytes += x.numel() * x.element_size() + dy.numel() * dy.element_size()
+        if self.bytes > WGRAD_GROUP_MAX_BYTES:
+            q, self.queue, self.bytes = self.queue, [], 0
+            nv.linear_wgrad_group(q)
 
     def flush(self):
-        q, self.queue = self.queue, []
+        q, self.queue, self.bytes = self.queue, [], 0
         r, self.redq = self.redq, []
         nv.linear_wgrad_group(q)
         nv.group_partial_sums(r)
@@ -659,7 +672,7 @@ def _linear_backward(x, w16, dgrad_nt, w_dtype, has_bias, stage, dy, need_x, nee
             if stage is not None and w_dtype == torch.float32:
                 # queued: the stage's identity node launches the whole group when the backward chain leaves the stage
                 dw, db_ = nv.linear_wgrad_alloc(k, dy.shape[1], want_db, x.device)
-                stage.queue.append((x, dy, dw, db_))
+                stage.add(x, dy, dw, db_)
                 if want_db:
                     db, want_db = db_, False
             elif want_db:                    # column sums of dy ride along in the wgrad kernel

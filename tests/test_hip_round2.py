@@ -544,8 +544,10 @@ def test_grouped_stage_wgrads_equal_per_layer_launches(monkeypatch):
     from scenesplat_amd import native as nv
     d = _tiny_input(40, 2)
     grads = {}
-    for mode, cap in (("grouped", 32768), ("single", 0)):
+    for mode, cap in (("grouped", 32768), ("byte_capped", 32768), ("single", 0)):
         monkeypatch.setattr(SF, "WGRAD_GROUP_MAX_ROWS", cap)
+        # byte_capped: the stage launches what it holds whenever the queued operands exceed the cap (here: nearly every layer)
+        monkeypatch.setattr(SF, "WGRAD_GROUP_MAX_BYTES", 200_000 if mode == "byte_capped" else 8 << 30)
         model = _tiny_lang().train()
         calls = []
         orig = nv.linear_wgrad_group
@@ -559,11 +561,15 @@ def test_grouped_stage_wgrads_equal_per_layer_launches(monkeypatch):
         grads[mode] = {k: p.grad.clone() for k, p in model.named_parameters()}
         if mode == "grouped":
             assert sum(calls) >= 10 and len(calls) <= 5, calls         # a handful of launches carry the stage's Linears
+            n_items = sum(calls)
+        elif mode == "byte_capped":
+            assert sum(calls) == n_items and len([c for c in calls if c]) > 5, calls     # the same layers in more, smaller groups
         else:
             assert not calls
     for k in grads["single"]:
-        a, b = grads["grouped"][k], grads["single"][k]
-        assert a.dtype == b.dtype and (a - b).norm() <= 2e-3 * b.norm() + 1e-7, (k, (a - b).norm() / b.norm())
+        for mode in ("grouped", "byte_capped"):
+            a, b = grads[mode][k], grads["single"][k]
+            assert a.dtype == b.dtype and (a - b).norm() <= 2e-3 * b.norm() + 1e-7, (mode, k, (a - b).norm() / b.norm())
 
 
 # ---- steady-state hipGraph replay (scenesplat_amd/steady_state.py) --------------------------------------------
