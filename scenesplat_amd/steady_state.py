@@ -176,6 +176,7 @@ class SteadyStateStep:
             with torch.cuda.stream(side):
                 cap.graph.capture_begin(capture_error_mode="thread_local")
                 try:
+                    cap.keep.open_capture(torch.cuda.current_device())     # one upload node for every descriptor table of the step
                     cap.outputs = {k: v.detach() for k, v in self.fn(cap.plan, cap.inputs).items()}
                 except BaseException as e:
                     if os.environ.get("SS_STEADY_DEBUG"):

@@ -48,6 +48,14 @@ for k, (t, c) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:40]:
     print("   %8.1f us %4d  %s" % (t / 1e3, c, k))
 small = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in main if int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) < 20000]
 print("launches shorter than 20 us: %d, %.2f ms in total" % (len(small), sum(small) / 1e6))
+sm = collections.defaultdict(lambda: [0, 0])
+for r in main:
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    if d < 20000:
+        k = r["Kernel_Name"].split("(")[0][-56:]
+        sm[k][0] += d; sm[k][1] += 1
+for k, (tt, c) in sorted(sm.items(), key=lambda kv: -kv[1][0])[:32]:
+    print("   small: %7.1f us %4d  %s" % (tt / 1e3, c, k))
 oth = [r for r in step if r[qkey] != mainq]
 if oth:
     offs = sorted((int(r["Start_Timestamp"]) - t0) / 1e6 for r in oth)
