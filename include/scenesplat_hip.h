@@ -154,6 +154,14 @@ int ss_subm_im2col(const void* src, const int32_t* nbr, void* dst, int64_t n, in
 int ss_gemm8_ok(int64_t m, int k, int n, int taps);
 int ss_subm_conv_fwd_pipe(const void* in, const void* weight, const float* bias, const int32_t* nbr, const int32_t* rowperm,
                           void* out, int64_t n, int cin, int cout, int taps, int out_dtype, ss_stream_t stream);
+/* the rulebook in WALK order (nbr_walk[t][k] = nbr[t][rowperm[k]]; rowperm NULL: nbr itself): the pipeline kernel then reads its
+ * 256-site slice as contiguous words.  ss_subm_conv_fwd_walk = ss_subm_conv_fwd that hands nbr_walk to the pipeline kernel when it
+ * dispatches there (ss_subm_conv_fwd_uses_pipe) and nbr to the other kernels; nbr_walk NULL: plain ss_subm_conv_fwd. */
+int ss_subm_conv_fwd_pipe_walk(const void* in, const void* weight, const float* bias, const int32_t* nbr_walk, const int32_t* rowperm,
+                               void* out, int64_t n, int cin, int cout, int taps, int out_dtype, ss_stream_t stream);
+int ss_subm_conv_fwd_uses_pipe(int64_t n, int cin, int cout, int taps);
+int ss_subm_conv_fwd_walk(const void* in, const void* weight, const float* bias, const int32_t* nbr, const int32_t* nbr_walk,
+                          const int32_t* rowperm, void* out, int64_t n, int cin, int cout, int taps, int out_dtype, ss_stream_t stream);
 int ss_linear_fwd(const void* x, const void* weight, const float* bias, void* out, int64_t m, int k, int n, int out_dtype,
                   ss_stream_t stream);
 /* weight gradients on the same pipeline (csrc/wgrad8.hip); dweight must be ZERO on entry (fp32 atomics).
@@ -202,6 +210,15 @@ int ss_subm_f32_fwd(const float* in, const float* wq, const float* bias, const i
 int ss_subm_f32_wgrad(const float* in, const float* dout, const int32_t* nbr_walk, const int32_t* rowperm,
                       const int32_t* blk_count, const int32_t* blk_list, float* dweight, int64_t n, int cin_padded,
                       int cin, int cout, int taps, ss_stream_t stream);
+
+/* weight gradient with the walk-order rulebook beside the plain one (see ss_subm_conv_fwd_walk); nbr_walk NULL = ss_subm_conv_wgrad */
+int ss_subm_conv_wgrad_pipe_walk(const void* in, const void* dout, const int32_t* nbr_walk, const int32_t* rowperm,
+                                 const int32_t* blk_count, const int32_t* blk_list, float* dweight, int64_t n, int cin, int cout,
+                                 int taps, ss_stream_t stream);
+int ss_subm_conv_wgrad_uses_pipe(int64_t n, int cin, int cout, int taps);
+int ss_subm_conv_wgrad_walk(const void* in, const void* dout, const int32_t* nbr, const int32_t* nbr_walk, const int32_t* rowperm,
+                            const int32_t* blk_count, const int32_t* blk_list, float* dweight, int64_t n, int cin, int cout,
+                            int taps, ss_stream_t stream);
 
 /* ---- fused residual add (+ DropPath row scale) + LayerNorm (ptv3:318-338 seams) ------------------------
  * v = x + rowscale*y; xout = v (f32/bf16) [+ bf16 copy]; h = LN(v)*gamma+beta.  NULL = absent.  C % 4 == 0, C <= 1024. */

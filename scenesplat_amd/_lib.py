@@ -72,6 +72,12 @@ PROTOTYPES = {
     "ss_subm_conv_fwd_splitk": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "ss_subm_block_lists": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_p, c_p]),
     "ss_subm_conv_wgrad": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
+    "ss_subm_conv_fwd_pipe_walk": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p]),
+    "ss_subm_conv_fwd_uses_pipe": (c_i, [c_i64, c_i, c_i, c_i]),
+    "ss_subm_conv_fwd_walk": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p]),
+    "ss_subm_conv_wgrad_pipe_walk": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
+    "ss_subm_conv_wgrad_uses_pipe": (c_i, [c_i64, c_i, c_i, c_i]),
+    "ss_subm_conv_wgrad_walk": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "ss_subm_f32_ok": (c_i, [c_i, c_i]),
     "ss_subm_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "ss_subm_f32_wgrad": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p]),

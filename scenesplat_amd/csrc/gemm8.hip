@@ -62,7 +62,7 @@ template <bool GATHER, typename OutT, bool HM = false>
 __global__ void __launch_bounds__(512)
 k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, const float* __restrict__ bias,
         const int32_t* __restrict__ nbr, const int32_t* __restrict__ rowperm, OutT* __restrict__ out, int M, int K,
-        int N, int taps, int ntn, int hm_c = 0, int hm_d = 0, float hm_scale = 1.f) {
+        int N, int taps, int ntn, int hm_c = 0, int hm_d = 0, float hm_scale = 1.f, int walk = 0) {
   __shared__ __attribute__((aligned(16))) char smem[G8_LDS_BYTES];   // ONE object: tiles + rulebook slice
   int32_t* nbr_s = reinterpret_cast<int32_t*>(smem + G8_OFF_NBR);
   int32_t* rowid_s = reinterpret_cast<int32_t*>(smem + G8_OFF_ROWID);
@@ -86,12 +86,32 @@ k_gemm8(const unsigned short* __restrict__ A, const unsigned short* __restrict__
     }
     if (tid == 0) *mask_s = 0u;
     __syncthreads();
-    for (int e = tid; e < taps * 256; e += 512) {
-      int tt = e >> 8, r = e & 255;            // tt is wave-uniform
-      int row = rowid_s[r];
-      int v = row >= 0 ? nbr[(int64_t)tt * M + row] : -1;
-      nbr_s[e] = v;
-      if (__ballot(v >= 0) != 0ULL && lane == 0) atomicOr(mask_s, 1u << tt);
+    // the tile's rulebook slice: taps x 256 words, ALL loads in flight before the first use (a load + ballot per iteration made
+    // this prologue 14 dependent round trips, 6-10 % of a workgroup's life at dec0).  walk != 0: nbr is the rulebook in WALK order
+    // (nbr_walk[t][k] = nbr[t][rowperm[k]], ScenePlan.neighbors_walk): a wave reads 256 contiguous bytes instead of 64 cache lines
+    constexpr int NIT = (G8_TAPS_MAX * 256 + 511) / 512;
+    int vals[NIT];
+    const int last = taps * 256 - 1;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = min(it * 512 + tid, last), tt = e >> 8, r = e & 255;
+      if (walk) {
+        const int k = m0 + r;
+        const int v = nbr[(int64_t)tt * M + min(k, M - 1)];
+        vals[it] = k < M ? v : -1;
+      } else {
+        const int row = rowid_s[r];
+        const int v = nbr[(int64_t)tt * M + max(row, 0)];
+        vals[it] = row >= 0 ? v : -1;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = it * 512 + tid;              // e >> 8 is wave-uniform
+      if (e <= last) {
+        nbr_s[e] = vals[it];
+        if (__ballot(vals[it] >= 0) != 0ULL && lane == 0) atomicOr(mask_s, 1u << (e >> 8));
+      }
     }
     __syncthreads();
     rem = __builtin_amdgcn_readfirstlane(*mask_s);
@@ -311,15 +331,15 @@ extern "C" int ss_gemm8_ok(int64_t m, int k, int n, int taps) {
 
 template <bool GATHER>
 static int g8_launch(const void* a, const void* w, const float* bias, const int32_t* nbr, const int32_t* rowperm, void* out,
-                     int64_t m, int k, int n, int taps, int out_dtype, hipStream_t stream) {
+                     int64_t m, int k, int n, int taps, int out_dtype, hipStream_t stream, int walk = 0) {
   if (!ss_gemm8_ok(m, k, n, taps)) return SS_ERR_ARG;
   const int ntm = ss_div_up(m, 256), ntn = ss_div_up(n, 256);
   dim3 grid(ntm * ntn), block(512);
   const unsigned short* A = (const unsigned short*)a; const unsigned short* Wp = (const unsigned short*)w;
   if (out_dtype == SS_BF16)
-    SS_LAUNCH((k_gemm8<GATHER, unsigned short>), grid, block, 0, stream, A, Wp, bias, nbr, rowperm, (unsigned short*)out, (int)m, k, n, taps, ntn);
+    SS_LAUNCH((k_gemm8<GATHER, unsigned short>), grid, block, 0, stream, A, Wp, bias, nbr, rowperm, (unsigned short*)out, (int)m, k, n, taps, ntn, 0, 0, 1.f, walk);
   else if (out_dtype == SS_F32)
-    SS_LAUNCH((k_gemm8<GATHER, float>), grid, block, 0, stream, A, Wp, bias, nbr, rowperm, (float*)out, (int)m, k, n, taps, ntn);
+    SS_LAUNCH((k_gemm8<GATHER, float>), grid, block, 0, stream, A, Wp, bias, nbr, rowperm, (float*)out, (int)m, k, n, taps, ntn, 0, 0, 1.f, walk);
   else
     return SS_ERR_ARG;
   return SS_OK;
@@ -330,6 +350,14 @@ extern "C" int ss_subm_conv_fwd_pipe(const void* in, const void* weight, const f
                                      int out_dtype, hipStream_t stream) {
   if (n == 0) return SS_OK;
   return g8_launch<true>(in, weight, bias, nbr, rowperm, out, n, cin, cout, taps, out_dtype, stream);
+}
+
+// the same kernel reading the rulebook in WALK order: nbr_walk[t][k] = nbr[t][rowperm[k]] (rowperm NULL: nbr itself)
+extern "C" int ss_subm_conv_fwd_pipe_walk(const void* in, const void* weight, const float* bias, const int32_t* nbr_walk,
+                                          const int32_t* rowperm, void* out, int64_t n, int cin, int cout, int taps,
+                                          int out_dtype, hipStream_t stream) {
+  if (n == 0) return SS_OK;
+  return g8_launch<true>(in, weight, bias, nbr_walk, rowperm, out, n, cin, cout, taps, out_dtype, stream, 1);
 }
 
 extern "C" int ss_linear_fwd(const void* x, const void* weight, const float* bias, void* out, int64_t m, int k, int n,

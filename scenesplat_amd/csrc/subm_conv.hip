@@ -448,6 +448,24 @@ extern "C" int ss_subm_conv_fwd(const void* in, const void* weight, const float*
   return SS_ERR_ARG;
 }
 
+static bool conv_fwd_uses_pipe(int64_t n, int cin, int cout, int taps) {
+  return ss_gemm8_ok(n, cin, cout, taps) && conv_pipe_mode() != 0 &&
+         (conv_pipe_mode() == 1 || (cout >= 256 && (int64_t)ss_div_up(n, 256) * ss_div_up(cout, 256) >= SS_CONV_BIG_MIN_TILES));
+}
+extern "C" int ss_subm_conv_fwd_uses_pipe(int64_t n, int cin, int cout, int taps) { return conv_fwd_uses_pipe(n, cin, cout, taps) ? 1 : 0; }
+
+// ss_subm_conv_fwd with the walk-order rulebook beside the plain one: the pipeline kernel (wide, large levels) reads nbr_walk,
+// the other kernels nbr.  nbr_walk NULL: ss_subm_conv_fwd.
+extern "C" int ss_subm_conv_fwd_walk(const void* in, const void* weight, const float* bias, const int32_t* nbr,
+                                     const int32_t* nbr_walk, const int32_t* rowperm, void* out, int64_t n, int cin, int cout,
+                                     int taps, int out_dtype, hipStream_t stream) {
+  if (n < 0 || cin <= 0 || cout <= 0 || taps <= 0 || (cin & 7) || n >= (1LL << 31)) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  if (nbr_walk && conv_fwd_uses_pipe(n, cin, cout, taps))
+    return ss_subm_conv_fwd_pipe_walk(in, weight, bias, nbr_walk, rowperm, out, n, cin, cout, taps, out_dtype, stream);
+  return ss_subm_conv_fwd(in, weight, bias, nbr, rowperm, out, n, cin, cout, taps, out_dtype, stream);
+}
+
 // split-K form for small levels: acc32 (n, cout) f32 must be zero on entry and receives out (+ bias); `splits`
 // tap ranges run as separate workgroups.  ss_subm_conv_splits() is the recommended count (1 = use ss_subm_conv_fwd).
 extern "C" int ss_subm_conv_splits(int64_t n, int cout, int taps) {
@@ -467,16 +485,32 @@ extern "C" int ss_subm_conv_fwd_splitk(const void* in, const void* weight, const
                                  (int)n, cin, cout, taps, stream, acc32, splits);
 }
 
+static bool conv_wgrad_uses_pipe(int64_t n, int cin, int cout, int taps) {
+  static int mode = -2;                 // SS_WGRAD_PIPE=0/1 overrides the kernel choice
+  if (mode == -2) { const char* e = getenv("SS_WGRAD_PIPE"); mode = e ? atoi(e) : -1; }
+  return mode != 0 && ss_wgrad8_ok(n, cin, cout, taps) && (mode == 1 || (cout >= 128 && cin >= 128));
+}
+extern "C" int ss_subm_conv_wgrad_uses_pipe(int64_t n, int cin, int cout, int taps) { return conv_wgrad_uses_pipe(n, cin, cout, taps) ? 1 : 0; }
+
+extern "C" int ss_subm_conv_wgrad_walk(const void* in, const void* dout, const int32_t* nbr, const int32_t* nbr_walk,
+                                       const int32_t* rowperm, const int32_t* blk_count, const int32_t* blk_list, float* dweight,
+                                       int64_t n, int cin, int cout, int taps, hipStream_t stream);
+
 extern "C" int ss_subm_conv_wgrad(const void* in, const void* dout, const int32_t* nbr, const int32_t* rowperm,
                                   const int32_t* blk_count, const int32_t* blk_list, float* dweight, int64_t n, int cin,
                                   int cout, int taps, hipStream_t stream) {
+  return ss_subm_conv_wgrad_walk(in, dout, nbr, nullptr, rowperm, blk_count, blk_list, dweight, n, cin, cout, taps, stream);
+}
+
+// nbr_walk (may be NULL): the rulebook in walk order, read by the pipeline kernel when the shape runs on it
+extern "C" int ss_subm_conv_wgrad_walk(const void* in, const void* dout, const int32_t* nbr, const int32_t* nbr_walk,
+                                       const int32_t* rowperm, const int32_t* blk_count, const int32_t* blk_list, float* dweight,
+                                       int64_t n, int cin, int cout, int taps, hipStream_t stream) {
   if (n < 0 || cin <= 0 || cout <= 0 || taps <= 0 || (cin & 7) || (cout & 7) || n >= (1LL << 31)) return SS_ERR_ARG;
   if (n == 0) return SS_OK;
-  {
-    static int mode = -2;                 // SS_WGRAD_PIPE=0/1 overrides the kernel choice
-    if (mode == -2) { const char* e = getenv("SS_WGRAD_PIPE"); mode = e ? atoi(e) : -1; }
-    if (mode != 0 && ss_wgrad8_ok(n, cin, cout, taps) && (mode == 1 || (cout >= 128 && cin >= 128)))
-      return ss_subm_conv_wgrad_pipe(in, dout, nbr, rowperm, blk_count, blk_list, dweight, n, cin, cout, taps, stream);
+  if (conv_wgrad_uses_pipe(n, cin, cout, taps)) {
+    if (nbr_walk) return ss_subm_conv_wgrad_pipe_walk(in, dout, nbr_walk, rowperm, blk_count, blk_list, dweight, n, cin, cout, taps, stream);
+    return ss_subm_conv_wgrad_pipe(in, dout, nbr, rowperm, blk_count, blk_list, dweight, n, cin, cout, taps, stream);
   }
   const int nblocks = ss_div_up(n, 64);
   // the 256 x 256 form pays off only with long K loops per workgroup (its fp32-atomic epilogue is 4x larger)

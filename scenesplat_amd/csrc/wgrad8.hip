@@ -56,7 +56,7 @@ __device__ __forceinline__ void
 w8_body(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY, const int32_t* __restrict__ nbr,
         const int32_t* __restrict__ rowperm, const int32_t* __restrict__ blk_count, const int32_t* __restrict__ blk_list,
         float* __restrict__ dW, float* __restrict__ dbias, int n, int Cin, int Cout, int taps, int ntn, int nblocks_total,
-        int min_per, int ntiles, int nshares, const int L) {
+        int min_per, int ntiles, int nshares, const int L, const int walk = 0) {
   __shared__ __attribute__((aligned(16))) char smem[GATHER ? W8_LDS_BYTES : 2 * W8_BUF];
   int32_t* isite_s = reinterpret_cast<int32_t*>(smem + W8_OFF_ISITE);
   int32_t* jsite_s = reinterpret_cast<int32_t*>(smem + W8_OFF_JSITE);
@@ -195,11 +195,43 @@ w8_body(const unsigned short* __restrict__ X, const unsigned short* __restrict__
     T = GATHER ? min(W8_CHUNK, end - chunk_beg) : end - chunk_beg;
     if (GATHER) {
       __syncthreads();                           // previous chunk's index reads are done
-      for (int e = tid; e < T * 64; e += 512) {
-        int k = list[chunk_beg + (e >> 6)] * 64 + (e & 63);
-        int is = k < n ? (rowperm ? rowperm[k] : k) : -1;
-        isite_s[e] = is;
-        jsite_s[e] = is >= 0 ? nbr[(int64_t)tap * n + is] : -1;
+      // the chunk's (site, neighbour) pairs: block id -> walk position k -> site rowperm[k] -> neighbour nbr[tap][site], a load +
+      // use per element = 24 serial round trips per chunk (15-19 % of a chunk's time at dec0).  walk != 0: nbr is in WALK order
+      // (nbr_walk[t][k] = nbr[t][rowperm[k]]): the neighbour does not wait for the site, a wave reads 256 contiguous bytes of it,
+      // and the two levels are batched four elements deep (more costs registers the K loop needs)
+      if (walk) {
+        constexpr int NH = 4;                                      // 4 x 512 elements per batch, two batches per chunk
+        for (int e0 = 0; e0 < T * 64; e0 += NH * 512) {
+          int kk[NH], is_[NH], js_[NH];
+          const int laste = T * 64 - 1;
+#pragma unroll
+          for (int it = 0; it < NH; ++it) {
+            const int e = min(e0 + it * 512 + tid, laste);
+            kk[it] = list[chunk_beg + (e >> 6)] * 64 + (e & 63);
+          }
+#pragma unroll
+          for (int it = 0; it < NH; ++it) {
+            const int kc = min(kk[it], n - 1);
+            is_[it] = rowperm ? rowperm[kc] : kc;
+            js_[it] = nbr[(int64_t)tap * n + kc];
+          }
+#pragma unroll
+          for (int it = 0; it < NH; ++it) {
+            const int e = e0 + it * 512 + tid;
+            if (e <= laste) {
+              const bool ok = kk[it] < n;
+              isite_s[e] = ok ? is_[it] : -1;
+              jsite_s[e] = ok ? js_[it] : -1;
+            }
+          }
+        }
+      } else {
+        for (int e = tid; e < T * 64; e += 512) {
+          int k = list[chunk_beg + (e >> 6)] * 64 + (e & 63);
+          int is = k < n ? (rowperm ? rowperm[k] : k) : -1;
+          isite_s[e] = is;
+          jsite_s[e] = is >= 0 ? nbr[(int64_t)tap * n + is] : -1;
+        }
       }
       __syncthreads();
     }
@@ -291,9 +323,9 @@ __global__ void __launch_bounds__(512)
 k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY, const int32_t* __restrict__ nbr,
          const int32_t* __restrict__ rowperm, const int32_t* __restrict__ blk_count, const int32_t* __restrict__ blk_list,
          float* __restrict__ dW, float* __restrict__ dbias, int n, int Cin, int Cout, int taps, int ntn, int nblocks_total,
-         int min_per, int ntiles, int nshares) {
+         int min_per, int ntiles, int nshares, int walk) {
   w8_body<GATHER>(X, DY, nbr, rowperm, blk_count, blk_list, dW, dbias, n, Cin, Cout, taps, ntn, nblocks_total, min_per, ntiles,
-                  nshares, (int)blockIdx.x);
+                  nshares, (int)blockIdx.x, walk);
 }
 
 // Grouped nn.Linear weight gradients: ONE launch for many independent problems (the six identical blocks of a pooled
@@ -329,9 +361,23 @@ static int w8_min_per(int64_t busy_tiles, int64_t est_blocks) {
   return (int)per;
 }
 
+static int w8_conv_launch(const void* in, const void* dout, const int32_t* nbr, const int32_t* rowperm, const int32_t* blk_count,
+                          const int32_t* blk_list, float* dweight, int64_t n, int cin, int cout, int taps, int walk, hipStream_t stream);
+
 extern "C" int ss_subm_conv_wgrad_pipe(const void* in, const void* dout, const int32_t* nbr, const int32_t* rowperm,
                                        const int32_t* blk_count, const int32_t* blk_list, float* dweight, int64_t n,
                                        int cin, int cout, int taps, hipStream_t stream) {
+  return w8_conv_launch(in, dout, nbr, rowperm, blk_count, blk_list, dweight, n, cin, cout, taps, 0, stream);
+}
+// the same kernel reading the rulebook in WALK order (nbr_walk[t][k] = nbr[t][rowperm[k]]; blk_* as before)
+extern "C" int ss_subm_conv_wgrad_pipe_walk(const void* in, const void* dout, const int32_t* nbr_walk, const int32_t* rowperm,
+                                            const int32_t* blk_count, const int32_t* blk_list, float* dweight, int64_t n,
+                                            int cin, int cout, int taps, hipStream_t stream) {
+  return w8_conv_launch(in, dout, nbr_walk, rowperm, blk_count, blk_list, dweight, n, cin, cout, taps, 1, stream);
+}
+
+static int w8_conv_launch(const void* in, const void* dout, const int32_t* nbr, const int32_t* rowperm, const int32_t* blk_count,
+                          const int32_t* blk_list, float* dweight, int64_t n, int cin, int cout, int taps, int walk, hipStream_t stream) {
   if (n == 0) return SS_OK;
   if (!ss_wgrad8_ok(n, cin, cout, taps) || !blk_count || !blk_list || !nbr) return SS_ERR_ARG;
   const int nblocks = ss_div_up(n, 64);
@@ -344,7 +390,7 @@ extern "C" int ss_subm_conv_wgrad_pipe(const void* in, const void* dout, const i
   int splits = ss_div_up(nblocks, min_per);
   dim3 g((unsigned)((int64_t)taps * splits * tm * tn));
   SS_LAUNCH((k_wgrad8<true>), g, dim3(512), 0, stream, (const unsigned short*)in, (const unsigned short*)dout, nbr, rowperm,
-            blk_count, blk_list, dweight, (float*)nullptr, (int)n, cin, cout, taps, tn, nblocks, min_per, tm * tn, splits);
+            blk_count, blk_list, dweight, (float*)nullptr, (int)n, cin, cout, taps, tn, nblocks, min_per, tm * tn, splits, walk);
   return SS_OK;
 }
 
@@ -410,6 +456,6 @@ extern "C" int ss_linear_wgrad(const void* x, const void* dy, float* dweight, fl
   dim3 g((unsigned)(splits * tm * tn));
   SS_LAUNCH((k_wgrad8<false>), g, dim3(512), 0, stream, (const unsigned short*)x, (const unsigned short*)dy,
             (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, dweight,
-            dbias, (int)m, k_in, n_out, 1, tn, nblocks, min_per, tm * tn, splits);
+            dbias, (int)m, k_in, n_out, 1, tn, nblocks, min_per, tm * tn, splits, 0);
   return SS_OK;
 }

@@ -156,7 +156,7 @@ class _SubMConv3dFused(torch.autograd.Function):
     (same kernel, tap-mirrored transposed weights) and wgrad; duplicate voxels handled exactly."""
 
     @staticmethod
-    def forward(ctx, feat, weight, bias, nbr, rowperm, blocks_fn, has_dup):
+    def forward(ctx, feat, weight, bias, nbr, rowperm, blocks_fn, has_dup, walk_fn=None):
         taps, n = nbr.shape
         cout, cin = weight.shape[0], weight.shape[-1]
         pad = (-cin) % 8
@@ -179,13 +179,19 @@ class _SubMConv3dFused(torch.autograd.Function):
             out = torch.nn.functional.linear(cols, w.view(cout, -1), bf16_of(bias))
             ctx.save_for_backward(cols, w, nbr, rowperm)
             return out.to(out_dtype)
-        out = nv.subm_conv_fwd(x, w, None if bias is None else bias.float().contiguous(), nbr, rowperm, out_dtype)
-        ctx.save_for_backward(x, w, nbr, rowperm)
+        # the pipeline kernel (wide, large levels) reads its rulebook slice in walk order when the level has one (plan.neighbors_walk)
+        walk = None
+        if walk_fn is not None and rowperm is not None and nv.subm_conv_fwd_uses_pipe(n, cin + pad, cout, taps):
+            walk = walk_fn()
+        ctx.has_walk = walk is not None
+        out = nv.subm_conv_fwd(x, w, None if bias is None else bias.float().contiguous(), nbr, rowperm, out_dtype, nbr_walk=walk)
+        ctx.save_for_backward(x, w, nbr, rowperm, *(() if walk is None else (walk,)))
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, w, nbr, rowperm = ctx.saved_tensors
+        x, w, nbr, rowperm = ctx.saved_tensors[:4]
+        walk = ctx.saved_tensors[4] if getattr(ctx, "has_walk", False) else None
         in_dtype, w_dtype, w_shape, cin, has_bias = ctx.meta
         g = dout.to(torch.bfloat16).contiguous()
         dx = dw = db = None
@@ -199,11 +205,11 @@ class _SubMConv3dFused(torch.autograd.Function):
                 dw = _mm_f32(g.t(), cols).view(w.shape)[:, :, :cin].reshape(w_shape).to(w_dtype)
             if has_bias and ctx.needs_input_grad[2]:
                 db = g.sum(0, dtype=torch.float32).to(w_dtype)
-            return dx, dw, db, None, None, None, None
+            return dx, dw, db, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             wt = ctx.wt if ctx.wt is not None else nv.subm_weight_mirror(w)       # [ci][t'][co] = w[co][T-1-t'][ci]
             if not ctx.has_dup:
-                dx = nv.subm_conv_fwd(g, wt, None, nbr, rowperm)[:, :cin].to(in_dtype)
+                dx = nv.subm_conv_fwd(g, wt, None, nbr, rowperm, nbr_walk=walk)[:, :cin].to(in_dtype)
             else:
                 # duplicate voxels (Mix3D batches): every site at a voxel reads the voxel's WINNER row, so the
                 # adjoint first folds the gradients of all duplicates onto their winner, runs the symmetric
@@ -215,10 +221,10 @@ class _SubMConv3dFused(torch.autograd.Function):
                 dx = (dx * is_w.unsqueeze(1)).to(in_dtype)
         if ctx.needs_input_grad[1]:
             blocks = ctx.blocks_fn() if ctx.blocks_fn is not None else nv.subm_block_lists(nbr, rowperm)
-            dw = nv.subm_conv_wgrad(x, g, nbr, rowperm, blocks)[:, :, :cin].reshape(w_shape).to(w_dtype)
+            dw = nv.subm_conv_wgrad(x, g, nbr, rowperm, blocks, nbr_walk=walk)[:, :, :cin].reshape(w_shape).to(w_dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = g.sum(0, dtype=torch.float32).to(w_dtype)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 def _split_bf16(t):
@@ -334,7 +340,7 @@ def subm_conv3d(feat, weight, bias, nbr, has_dup=False, compute_dtype=torch.floa
     matrix cores: exact fp32 MFMA for the 32-channel stage (walk_fn: the level's cached walk-order rulebook), else the bf16
     kernels on hi/lo-split operands; torch.float32 -> per-tap gather + fp32 GEMM."""
     if compute_dtype == torch.bfloat16 and weight.shape[0] % 8 == 0:
-        return _SubMConv3dFused.apply(feat, weight, bias, nbr, rowperm, blocks_fn, has_dup)
+        return _SubMConv3dFused.apply(feat, weight, bias, nbr, rowperm, blocks_fn, has_dup, walk_fn)
     if compute_dtype == "bf16x3":
         if (CONV_F32_MFMA and weight.shape[0] == 32 and weight.shape[-1] <= 32 and not has_dup and feat.is_cuda
                 and (weight.shape[-1] == 32 or not feat.requires_grad)):

@@ -239,8 +239,14 @@ def subm_tap_mask_keys(nbr, order, coarse_bits):
     return keys
 
 
-def subm_conv_fwd(x, w, bias, nbr, rowperm, out_dtype=torch.bfloat16):
-    """x (n,cin) bf16, w (cout,taps,cin) bf16, bias (cout) f32|None, nbr (taps,n) -> (n,cout)."""
+def subm_conv_fwd_uses_pipe(n, cin, cout, taps):
+    """Does subm_conv_fwd run this shape on the pipeline kernel (the one that profits from a walk-order rulebook)?"""
+    return bool(lib().ss_subm_conv_fwd_uses_pipe(n, cin, cout, taps)) and lib().ss_subm_conv_splits(n, cout, taps) <= 1
+
+
+def subm_conv_fwd(x, w, bias, nbr, rowperm, out_dtype=torch.bfloat16, nbr_walk=None):
+    """x (n,cin) bf16, w (cout,taps,cin) bf16, bias (cout) f32|None, nbr (taps,n) -> (n,cout).
+    nbr_walk: the rulebook in walk order (subm_walk_rulebook), read by the pipeline kernel where the shape runs on it."""
     n, cin = x.shape
     cout, taps, cin2 = w.shape
     _req(x, torch.bfloat16, "x"); _req(w, torch.bfloat16, "w"); _req(nbr, torch.int32, "nbr", (taps, n))
@@ -257,6 +263,11 @@ def subm_conv_fwd(x, w, bias, nbr, rowperm, out_dtype=torch.bfloat16):
                                             _stream()), "ss_subm_conv_fwd_splitk")
         return acc if out_dtype == torch.float32 else acc.to(out_dtype)
     out = torch.empty((n, cout), dtype=out_dtype, device=x.device)
+    if nbr_walk is not None:
+        _req(nbr_walk, torch.int32, "nbr_walk", (taps, n))
+        check(lib().ss_subm_conv_fwd_walk(_p(x), _p(w), _p(bias), _p(nbr), _p(nbr_walk), _p(rowperm), _p(out), n, cin, cout, taps,
+                                          dtype_code(out), _stream()), "ss_subm_conv_fwd_walk")
+        return out
     check(lib().ss_subm_conv_fwd(_p(x), _p(w), _p(bias), _p(nbr), _p(rowperm), _p(out), n, cin, cout, taps,
                                  dtype_code(out), _stream()), "ss_subm_conv_fwd")
     return out
@@ -337,9 +348,10 @@ def zeros_f32(numel, device):
     return torch.zeros(int(numel), dtype=torch.float32, device=device)
 
 
-def subm_conv_wgrad(x, dout, nbr, rowperm, blocks, out=None):
+def subm_conv_wgrad(x, dout, nbr, rowperm, blocks, out=None, nbr_walk=None):
     """-> dW (cout,taps,cin) f32 = sum_i dout[i] (x) x[nbr[t][i]].  blocks = subm_block_lists(nbr, rowperm).
-    out: a ZEROED (cout,taps,cin) f32 accumulator to add into (deferred launches)."""
+    out: a ZEROED (cout,taps,cin) f32 accumulator to add into (deferred launches).
+    nbr_walk: the rulebook in walk order (subm_walk_rulebook), read by the pipeline kernel where the shape runs on it."""
     n, cin = x.shape
     cout = dout.shape[1]
     taps = nbr.shape[0]
@@ -351,8 +363,10 @@ def subm_conv_wgrad(x, dout, nbr, rowperm, blocks, out=None):
     dw = zeros_f32(cout * taps * cin, x.device).view(cout, taps, cin) if out is None else _req(out, torch.float32, "out", (cout, taps, cin))
     cnt, lst = blocks
     _req(cnt, torch.int32, "blk_count", (taps,)); _req(lst, torch.int32, "blk_list", (taps, (n + 63) // 64))
-    check(lib().ss_subm_conv_wgrad(_p(x), _p(dout), _p(nbr), _p(rowperm), _p(cnt), _p(lst), _p(dw), n, cin, cout, taps,
-                                   _stream()), "ss_subm_conv_wgrad")
+    if nbr_walk is not None:
+        _req(nbr_walk, torch.int32, "nbr_walk", (taps, n))
+    check(lib().ss_subm_conv_wgrad_walk(_p(x), _p(dout), _p(nbr), _p(nbr_walk), _p(rowperm), _p(cnt), _p(lst), _p(dw), n, cin, cout, taps,
+                                        _stream()), "ss_subm_conv_wgrad")
     return dw
 
 

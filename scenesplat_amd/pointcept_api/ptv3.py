@@ -306,6 +306,7 @@ class PointTransformerV3(PointModule):
 
         ln_layer, act_layer = nn.LayerNorm, nn.GELU
         self.enc_channels = tuple(enc_channels)
+        self.dec_channels_ = tuple(dec_channels) if not cls_mode else ()        # width of the decoder stage at level s
         self.embedding = Embedding(in_channels, enc_channels[0], bn_layer, act_layer)
         blk = dict(mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=proj_drop,
                    norm_layer=ln_layer, act_layer=act_layer, pre_norm=pre_norm, enable_rpe=enable_rpe,
@@ -352,6 +353,12 @@ class PointTransformerV3(PointModule):
         K = len(self.order)
         # 32-channel convs at the reference's fp32 precision run on the fp32-MFMA kernels, which read the rulebook in walk order
         walk = [SF.CONV_F32_MFMA and c == 32 and conv_dtype_for(c) == "bf16x3" for c in self.enc_channels]
+        # ... and so does the bf16 pipeline conv of the wide stages (>= 256 channels on that level, encoder or decoder side)
+        wide = list(self.enc_channels)
+        if not self.cls_mode:
+            for s, c in enumerate(self.dec_channels_):
+                wide[s] = max(wide[s], c)
+        walk = [w or (c >= 256 and conv_dtype_for(c) == torch.bfloat16) for w, c in zip(walk, wide)]
         wins, ks = [], [(0, 5, walk[0])]
         for s in range(self.num_stages):
             enc = getattr(self.enc, f"enc{s}")

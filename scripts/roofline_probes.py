@@ -45,7 +45,7 @@ def build(n_side=256, which=None):
     want = lambda k: which is None or k in which
     probes = []
     if want("conv_fwd") or want("conv_wgrad"):
-        nbr, perm, blocks = lv.neighbors(3), lv.conv_rowperm(), lv.conv_blocks(3)
+        nbr, perm, blocks, walk = lv.neighbors(3), lv.conv_rowperm(), lv.conv_blocks(3), lv.neighbors_walk(3)   # as the step's launches
         x = torch.randn(lv.n, C, device="cuda", generator=g).to(torch.bfloat16)
         w = (torch.randn(C, 27, C, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
         go = torch.randn(lv.n, C, device="cuda", generator=g).to(torch.bfloat16)
@@ -54,10 +54,10 @@ def build(n_side=256, which=None):
         by = lv.n * C * 2 * 2 + 27 * C * C * 2
         note = "n=%d, C=%d, 27 taps, %.2f pairs/site" % (lv.n, C, pairs / lv.n)
         if want("conv_fwd"):
-            probes.append(dict(name="conv_fwd", kernel="k_gemm8", run=lambda: nv.subm_conv_fwd(x, w, None, nbr, perm), bound="mfma",
+            probes.append(dict(name="conv_fwd", kernel="k_gemm8", run=lambda: nv.subm_conv_fwd(x, w, None, nbr, perm, nbr_walk=walk), bound="mfma",
                                flops=fl, bytes=by, note="k_gemm8<true> subm conv fwd/dgrad (dec0: %s)" % note))
         if want("conv_wgrad"):
-            probes.append(dict(name="conv_wgrad", kernel="k_wgrad8", run=lambda: nv.subm_conv_wgrad(x, go, nbr, perm, blocks), bound="mfma",
+            probes.append(dict(name="conv_wgrad", kernel="k_wgrad8", run=lambda: nv.subm_conv_wgrad(x, go, nbr, perm, blocks, nbr_walk=walk), bound="mfma",
                                flops=fl, bytes=2 * lv.n * C * 2 + 27 * C * C * 4, note="k_wgrad8<true> subm conv wgrad (dec0: %s)" % note))
     if want("attn_fwd") or want("attn_bwd"):
         # the kernels the step runs since round 3: head-major, window-ordered q / k / v (csrc/attention_hm.hip)
