@@ -181,7 +181,7 @@ class _SubMConv3dFused(torch.autograd.Function):
             return out.to(out_dtype)
         # the pipeline kernel (wide, large levels) reads its rulebook slice in walk order when the level has one (plan.neighbors_walk)
         walk = None
-        if walk_fn is not None and rowperm is not None and nv.subm_conv_fwd_uses_pipe(n, cin + pad, cout, taps):
+        if CONV_WALK_RULEBOOK and walk_fn is not None and rowperm is not None and nv.subm_conv_fwd_uses_pipe(n, cin + pad, cout, taps):
             walk = walk_fn()
         ctx.has_walk = walk is not None
         out = nv.subm_conv_fwd(x, w, None if bias is None else bias.float().contiguous(), nbr, rowperm, out_dtype, nbr_walk=walk)
@@ -322,6 +322,7 @@ class _SubMConv3dF32(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+CONV_WALK_RULEBOOK = os.environ.get("SS_CONV_WALK", "1") != "0"    # 0: the pipeline conv kernels read the plain rulebook (A/B: scripts/ab_step.py conv_walk)
 CONV_F32_MFMA = os.environ.get("SS_CONV_F32_MFMA", "1") != "0"      # A/B switch against the bf16x3 split (scripts/ab_step.py)
 CONV_IM2COL_MAX_SITES = int(os.environ.get("SS_CONV_IM2COL_MAX", "8192"))
 

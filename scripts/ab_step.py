@@ -52,6 +52,8 @@ def setter(on):
         SF.SHADOW_GROUP_CAST = on
     elif which == "conv_f32":
         SF.CONV_F32_MFMA = on
+    elif which == "conv_walk":
+        SF.CONV_WALK_RULEBOOK = on
     elif which == "mask_small":
         import scenesplat_amd.plan as P
         P.CONV_MASK_MIN_SITES = 4096 if on else 16384

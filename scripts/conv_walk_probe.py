@@ -12,8 +12,12 @@ data = room_chunk(256, 0, lang_dim=0)
 plan = build_plan(data["grid_coord"].cuda(), data["offset"].cuda(), ("z", "z-trans", "hilbert", "hilbert-trans"), (2, 2, 2))
 
 
-def timeit(fn, reps=20):
-    for _ in range(3):
+REPS, WARM = (int(sys.argv[1]), int(sys.argv[1]) // 4) if len(sys.argv) > 1 else (20, 3)     # e.g. 300: sustained (power-limited) clocks
+
+
+def timeit(fn, reps=None):
+    reps = REPS if reps is None else reps
+    for _ in range(WARM):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
