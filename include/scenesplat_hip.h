@@ -238,6 +238,7 @@ int ss_add_layernorm_bwd_blocks(int64_t n);
 /* ONE launch reducing many partial-sum blocks (the dgamma / dbeta partials of a whole stage): desc (nprob, 4) int64 device =
  * {part (K, nb, C) f32, dst (K*C) f32, nb, C | (K*C) << 32}; wg_start (nprob + 1) int32 device, problem p owns
  * ceil(K*C / 256) workgroups; dst[k*C + c] = sum_b part[k][b][c]. */
+int ss_group_partial_sums_outputs_per_workgroup(void);   /* outputs (columns of K * C) one workgroup of ss_group_partial_sums owns */
 int ss_group_partial_sums(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups, ss_stream_t stream);
 /* ss_transpose16_group: dst (cols, rows) = src (rows, cols)^T of 2-byte elements for many matrices in one launch (transposed bf16 copies of
  * nn.Linear weights: hipBLASLt's NT form of the dgrad GEMM dx = dy @ W, reference call site torch.nn.functional.linear backward under

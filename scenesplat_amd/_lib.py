@@ -83,6 +83,7 @@ PROTOTYPES = {
     "ss_subm_f32_wgrad": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "ss_add_layernorm_fwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_p]),
     "ss_add_layernorm_bwd_blocks": (c_i, [c_i64]),
+    "ss_group_partial_sums_outputs_per_workgroup": (c_i, []),
     "ss_group_partial_sums": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "ss_transpose16_group": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "ss_subm_weight_mirror_group": (c_i, [c_p, c_p, c_i, c_i, c_p]),

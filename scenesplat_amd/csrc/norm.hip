@@ -664,8 +664,13 @@ extern "C" int ss_bn_act_bwd_apply(const void* dy, int dy_dtype, const void* x, 
 // vectors).  Reducing each with its own launch is 44 tiny kernels per step on the pooled levels; the stage identity node
 // (functional._StageParams) queues them and this kernel reduces ALL of a stage's partials in one launch.
 // desc: 4 int64 words per problem = {part, dst (K*C f32), nb, C | (K*C) << 32}; wg_start (nprob + 1): first workgroup.
+// A workgroup owns GPS_COLS consecutive outputs and splits the nb partial rows over 8 row groups (one thread per (output, group), LDS
+// reduce): the first form gave each output ONE thread that walked all nb <= 1024 rows -- a 256-step dependent chain on 60 workgroups,
+// 65 us per stage and 0.45 ms per step for a few MB of reads.
+#define GPS_COLS 32
 __global__ void __launch_bounds__(256)
 k_group_partial_sums(const int64_t* __restrict__ desc, const int32_t* __restrict__ wg_start, int nprob) {
+  __shared__ float red[8][GPS_COLS];
   const int b = blockIdx.x;
   int p = 0;
   while (p + 1 < nprob && wg_start[p + 1] <= b) ++p;
@@ -674,19 +679,29 @@ k_group_partial_sums(const int64_t* __restrict__ desc, const int32_t* __restrict
   float* dst = reinterpret_cast<float*>(d[1]);
   const int nb = (int)d[2];
   const int C = (int)((uint64_t)d[3] & 0xffffffffu), KC = (int)((uint64_t)d[3] >> 32);
-  const int j = (b - wg_start[p]) * 256 + threadIdx.x;
-  if (j >= KC) return;
-  const int k = j / C, c = j - k * C;
-  const float* src = part + (int64_t)k * nb * C + c;
+  const int cg = threadIdx.x & (GPS_COLS - 1), rg = threadIdx.x / GPS_COLS;
+  const int j = (b - wg_start[p]) * GPS_COLS + cg;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int bb = 0;
-  for (; bb + 4 <= nb; bb += 4) {
-    a0 += src[(int64_t)bb * C]; a1 += src[(int64_t)(bb + 1) * C]; a2 += src[(int64_t)(bb + 2) * C]; a3 += src[(int64_t)(bb + 3) * C];
+  if (j < KC) {
+    const int k = j / C, c = j - k * C;
+    const float* src = part + (int64_t)k * nb * C + c;
+    int bb = rg;
+    for (; bb + 24 < nb; bb += 32) {
+      a0 += src[(int64_t)bb * C]; a1 += src[(int64_t)(bb + 8) * C]; a2 += src[(int64_t)(bb + 16) * C]; a3 += src[(int64_t)(bb + 24) * C];
+    }
+    for (; bb < nb; bb += 8) a0 += src[(int64_t)bb * C];
   }
-  for (; bb < nb; ++bb) a0 += src[(int64_t)bb * C];
-  dst[j] = (a0 + a1) + (a2 + a3);
+  red[rg][cg] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (rg == 0 && j < KC) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += red[r][cg];
+    dst[j] = s;
+  }
 }
 
+extern "C" int ss_group_partial_sums_outputs_per_workgroup(void) { return GPS_COLS; }
 extern "C" int ss_group_partial_sums(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups,
                                      ss_stream_t stream) {
   if (nprob <= 0 || total_workgroups <= 0) return SS_OK;

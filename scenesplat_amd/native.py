@@ -541,11 +541,12 @@ def group_partial_sums(items):
     dev = items[0][0].device
     desc = np.zeros((len(items), 4), dtype=np.int64)
     starts = [0]
+    per = lib().ss_group_partial_sums_outputs_per_workgroup()
     for j, (part, dst) in enumerate(items):
         K, nb, C = part.shape
         _req(part, torch.float32, "part"); _req(dst, torch.float32, "dst", (K, C))
         desc[j] = (part.data_ptr(), dst.data_ptr(), nb, C | ((K * C) << 32))
-        starts.append(starts[-1] + (K * C + 255) // 256)
+        starts.append(starts[-1] + (K * C + per - 1) // per)
     d_dev, s_dev = _upload_descriptors(desc, starts, dev)
     check(lib().ss_group_partial_sums(_p(d_dev), _p(s_dev), len(items), starts[-1], _stream()), "ss_group_partial_sums")
 
