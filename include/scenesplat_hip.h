@@ -247,6 +247,7 @@ int ss_group_partial_sums(const int64_t* desc, const int32_t* wg_start, int npro
 int ss_transpose16_group(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups, ss_stream_t stream);
 /* ss_subm_weight_mirror_group: ss_subm_weight_mirror for many conv weights in one launch; desc (nprob, 5) int64 device = {w, wt, cout, taps,
  * cin}, wg_start = running total of taps * ceil(cout / 32) * ceil(cin / 32). */
+int ss_subm_weight_mirror_group_tile(void);   /* edge of the (cout x cin) tile one workgroup of ss_subm_weight_mirror_group owns */
 int ss_subm_weight_mirror_group(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups, ss_stream_t stream);
 /* g_v = g_xout + g_xcopy + LN'(g_h); g_x = g_v; g_y = rowscale*g_v; dgamma/dbeta partials (nblocks, C) */
 int ss_add_layernorm_bwd(const void* g_xout, int g_xout_dtype, const void* g_xcopy, int g_xcopy_dtype, const void* g_h,

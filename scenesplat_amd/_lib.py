@@ -86,6 +86,7 @@ PROTOTYPES = {
     "ss_group_partial_sums_outputs_per_workgroup": (c_i, []),
     "ss_group_partial_sums": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "ss_transpose16_group": (c_i, [c_p, c_p, c_i, c_i, c_p]),
+    "ss_subm_weight_mirror_group_tile": (c_i, []),
     "ss_subm_weight_mirror_group": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "ss_add_layernorm_bwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p,
                                    c_i64, c_i, c_i, c_p]),

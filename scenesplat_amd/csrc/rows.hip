@@ -493,10 +493,11 @@ extern "C" int ss_row_keep_scales(const int64_t* seed, const float* keep, float*
 }
 
 // ---- grouped form of k_subm_weight_mirror: the dgrad weights of ALL convs of a model in one launch (refreshed with the bf16 shadows) ----
-// desc: 5 int64 words per problem = {w, wt, cout, taps, cin}; wg_start (nprob + 1); a workgroup owns one (tap, 32 x 32) tile.
+// desc: 5 int64 words per problem = {w, wt, cout, taps, cin}; wg_start (nprob + 1); a workgroup owns one (tap, WMG_TILE x WMG_TILE) tile.
+#define WMG_TILE 64      // 64 x 64 elements: 128-byte rows on both the read and the write side (32 x 32 moved 64-byte half lines: 142 us per refresh)
 __global__ void __launch_bounds__(256)
 k_subm_weight_mirror_group(const int64_t* __restrict__ desc, const int32_t* __restrict__ wg_start, int nprob) {
-  __shared__ unsigned short tile[32][33];
+  __shared__ unsigned short tile[WMG_TILE][WMG_TILE + 2];
   const int b = blockIdx.x;
   int p = 0;
   while (p + 1 < nprob && wg_start[p + 1] <= b) ++p;
@@ -504,24 +505,25 @@ k_subm_weight_mirror_group(const int64_t* __restrict__ desc, const int32_t* __re
   const unsigned short* w = reinterpret_cast<const unsigned short*>(d[0]);
   unsigned short* wt = reinterpret_cast<unsigned short*>(d[1]);
   const int cout = (int)d[2], taps = (int)d[3], cin = (int)d[4];
-  const int tci = (cin + 31) >> 5, tco = (cout + 31) >> 5;
+  const int tci = (cin + WMG_TILE - 1) / WMG_TILE, tco = (cout + WMG_TILE - 1) / WMG_TILE;
   int l = b - wg_start[p];
-  const int ci0 = (l % tci) * 32; l /= tci;
-  const int co0 = (l % tco) * 32; const int t = l / tco;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-#pragma unroll
-  for (int r = ty; r < 32; r += 8) {
+  const int ci0 = (l % tci) * WMG_TILE; l /= tci;
+  const int co0 = (l % tco) * WMG_TILE; const int t = l / tco;
+  const int tx = threadIdx.x & (WMG_TILE - 1), ty = threadIdx.x / WMG_TILE;
+#pragma unroll 4
+  for (int r = ty; r < WMG_TILE; r += 256 / WMG_TILE) {
     int co = co0 + r, ci = ci0 + tx;
     tile[r][tx] = (co < cout && ci < cin) ? w[((int64_t)co * taps + t) * cin + ci] : (unsigned short)0;
   }
   __syncthreads();
-#pragma unroll
-  for (int r = ty; r < 32; r += 8) {
+#pragma unroll 4
+  for (int r = ty; r < WMG_TILE; r += 256 / WMG_TILE) {
     int ci = ci0 + r, co = co0 + tx;
     if (ci < cin && co < cout) wt[((int64_t)ci * taps + (taps - 1 - t)) * cout + co] = tile[tx][r];
   }
 }
 
+extern "C" int ss_subm_weight_mirror_group_tile(void) { return WMG_TILE; }
 extern "C" int ss_subm_weight_mirror_group(const int64_t* desc, const int32_t* wg_start, int nprob, int total_workgroups,
                                            hipStream_t stream) {
   if (nprob <= 0 || total_workgroups <= 0) return SS_OK;

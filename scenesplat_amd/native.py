@@ -559,11 +559,12 @@ def subm_weight_mirror_group(pairs):
     dev = pairs[0][0].device
     desc = np.zeros((len(pairs), 5), dtype=np.int64)
     starts = [0]
+    tile = lib().ss_subm_weight_mirror_group_tile()
     for j, (w, wt) in enumerate(pairs):
         cout, taps, cin = w.shape
         _req(w, torch.bfloat16, "w"); _req(wt, torch.bfloat16, "wt", (cin, taps, cout))
         desc[j] = (w.data_ptr(), wt.data_ptr(), cout, taps, cin)
-        starts.append(starts[-1] + taps * ((cout + 31) // 32) * ((cin + 31) // 32))
+        starts.append(starts[-1] + taps * ((cout + tile - 1) // tile) * ((cin + tile - 1) // tile))
     d_dev, s_dev = _upload_descriptors(desc, starts, dev)
     check(lib().ss_subm_weight_mirror_group(_p(d_dev), _p(s_dev), len(pairs), starts[-1], _stream()), "ss_subm_weight_mirror_group")
 
