@@ -6,7 +6,8 @@ cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 O=gpurun_out/r3p
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps 10 --warmup 3 --no-pmc --no-secondary --no-cpu-baseline > $O/stats.log 2>&1
+# (no replay/eager calibration in the traced run: its 16 extra steps would be in the per-step averages; the replay is what is traced)
+SS_BENCH_CALIBRATE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps 10 --warmup 3 --no-pmc --no-secondary --no-cpu-baseline > $O/stats.log 2>&1
 python - <<'PY'
 import csv, glob, collections, os
 O = "gpurun_out/r3p"
@@ -16,7 +17,7 @@ trace = max(glob.glob(O + "/stats/*/*kernel_trace.csv"), key=os.path.getsize)
 steps = 13.0
 rows = list(csv.DictReader(open(stats)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows); calls = sum(int(r["Calls"]) for r in rows)
-out = ["source: rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-pmc --no-secondary --no-cpu-baseline",
+out = ["source: SS_BENCH_CALIBRATE=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-pmc --no-secondary --no-cpu-baseline",
        f"GPU kernel time {tot / 1e6 / steps:.2f} ms/step, {calls / steps:.0f} launches/step (over {steps:g} steps incl. warm-up; the roofline probes and", 
        "the plan builds of the side stream are in the same trace)", "", "| ms/step | % | calls/step | avg us | kernel |", "|---|---|---|---|---|"]
 for r in rows[:45]:
