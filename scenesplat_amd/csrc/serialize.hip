@@ -80,13 +80,17 @@ __global__ void k_grid_max(const int32_t* __restrict__ gc, int64_t n3, int32_t* 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (int64_t)gridDim.x * blockDim.x)
     m = max(m, gc[i]);
   for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+  // one global atomic per workgroup (4,096 same-address atomics, one per wave of 1,024 workgroups, took 50 us)
+  __shared__ int wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, max(max(wm[0], wm[1]), max(wm[2], wm[3])));
 }
 extern "C" int ss_grid_coord_max(const int32_t* grid_coord, int64_t n, int32_t* out_max, hipStream_t stream) {
   if (n < 0) return SS_ERR_ARG;
   hipMemsetAsync(out_max, 0, sizeof(int32_t), stream);
   if (n == 0) return SS_OK;
-  int blocks = min(1024, ss_div_up(n * 3, 256));
+  int blocks = min(256, ss_div_up(n * 3, 256));
   SS_LAUNCH(k_grid_max, dim3(blocks), dim3(256), 0, stream, grid_coord, n * 3, out_max);
   SS_CHECK_LAUNCH();
   return SS_OK;
@@ -99,6 +103,7 @@ extern "C" int ss_grid_coord_max(const int32_t* grid_coord, int64_t n, int32_t* 
 #define RS_THREADS 256
 #define RS_ITEMS 8
 #define RS_TILE (RS_THREADS * RS_ITEMS)
+#define RS_STRIDE(num_tiles) (((num_tiles) + 3) & ~3)      // counters per digit row of the tile histogram
 
 __global__ void k_rs_hist(const int64_t* __restrict__ keys, int64_t n, int shift, uint32_t* __restrict__ tile_hist,
                           int num_tiles) {
@@ -114,14 +119,23 @@ __global__ void k_rs_hist(const int64_t* __restrict__ keys, int64_t n, int shift
     if (i < n) atomicAdd(&h[((uint64_t)kk[i] >> shift) & 255], 1u);
   }
   __syncthreads();
-  tile_hist[((int64_t)k * 256 + threadIdx.x) * num_tiles + tile] = h[threadIdx.x];
+  tile_hist[((int64_t)k * 256 + threadIdx.x) * RS_STRIDE(num_tiles) + tile] = h[threadIdx.x];
 }
 
+// digit-major rows of `stride` = num_tiles rounded up to 4 counters (16-byte loads; the pad entries are never written and are masked
+// here).  One thread per digit walks its row: with one 4-byte load per step this was 2 x 50 dependent-ish loads on ONE workgroup per
+// segment, 19 us per pass and 0.36 ms of every plan build; four counters per load and the loads of a row unrolled cut it to a third.
 __global__ void k_rs_scan(uint32_t* __restrict__ tile_hist, int num_tiles) {
   __shared__ uint32_t tot[256];
-  uint32_t* row = tile_hist + ((int64_t)blockIdx.x * 256 + threadIdx.x) * num_tiles;
+  const int n4 = RS_STRIDE(num_tiles) >> 2;
+  uint4* row = reinterpret_cast<uint4*>(tile_hist + ((int64_t)blockIdx.x * 256 + threadIdx.x) * RS_STRIDE(num_tiles));
   uint32_t s = 0;
-  for (int t = 0; t < num_tiles; ++t) s += row[t];
+#pragma unroll 8
+  for (int q = 0; q < n4; ++q) {
+    const uint4 c = row[q];
+    const int t = q * 4;
+    s += c.x + (t + 1 < num_tiles ? c.y : 0u) + (t + 2 < num_tiles ? c.z : 0u) + (t + 3 < num_tiles ? c.w : 0u);
+  }
   tot[threadIdx.x] = s;
   __syncthreads();
   // exclusive scan of 256 digit totals (Hillis-Steele)
@@ -133,7 +147,17 @@ __global__ void k_rs_scan(uint32_t* __restrict__ tile_hist, int num_tiles) {
     __syncthreads();
   }
   uint32_t run = v - s;
-  for (int t = 0; t < num_tiles; ++t) { uint32_t c = row[t]; row[t] = run; run += c; }
+#pragma unroll 8
+  for (int q = 0; q < n4; ++q) {
+    const uint4 c = row[q];
+    const int t = q * 4;
+    uint4 o;
+    o.x = run; run += c.x;
+    o.y = run; run += (t + 1 < num_tiles ? c.y : 0u);
+    o.z = run; run += (t + 2 < num_tiles ? c.z : 0u);
+    o.w = run; run += (t + 3 < num_tiles ? c.w : 0u);
+    row[q] = o;
+  }
 }
 
 __global__ void k_rs_scatter(const int64_t* __restrict__ keys_in, const int32_t* __restrict__ vals_in,
@@ -144,7 +168,7 @@ __global__ void k_rs_scatter(const int64_t* __restrict__ keys_in, const int32_t*
   __shared__ uint32_t wave_cnt[RS_THREADS / 64][256];
   const int k = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   const int64_t seg = (int64_t)k * n;
-  digit_base[tid] = tile_hist[((int64_t)k * 256 + tid) * num_tiles + tile];
+  digit_base[tid] = tile_hist[((int64_t)k * 256 + tid) * RS_STRIDE(num_tiles) + tile];
   const uint64_t lt_mask = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
   int64_t base = (int64_t)tile * RS_TILE;
   for (int r = 0; r < RS_ITEMS; ++r) {
@@ -187,7 +211,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 extern "C" size_t ss_argsort_workspace_bytes(int64_t n, int num_segments) {
   int num_tiles = ss_div_up(n > 0 ? n : 1, RS_TILE);
   return align256((size_t)num_segments * n * 8) * 2 + align256((size_t)num_segments * n * 4) * 2 +
-         align256((size_t)num_segments * 256 * num_tiles * 4);
+         align256((size_t)num_segments * 256 * RS_STRIDE(num_tiles) * 4);
 }
 
 extern "C" int ss_argsort_i64(const int64_t* keys, int num_segments, int64_t n, int key_bits, int32_t* order_out,

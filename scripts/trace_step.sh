@@ -63,6 +63,12 @@ if oth:
         offs[0], offs[len(offs) // 10], offs[len(offs) // 2], offs[len(offs) * 9 // 10], offs[-1], (t1 - t0) / 1e6))
     hist = collections.Counter(int(o // 2.0) * 2 for o in offs)
     print("   per 2-ms bin:", " ".join("%d:%d" % (k, hist[k]) for k in sorted(hist)))
+oa = collections.defaultdict(lambda: [0, 0])
+for r in oth:
+    k = r["Kernel_Name"].split("(")[0][-56:]
+    oa[k][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); oa[k][1] += 1
+for k, (tt, c) in sorted(oa.items(), key=lambda kv: -kv[1][0])[:16]:
+    print("   side: %7.1f us %4d  %s" % (tt / 1e3, c, k))
 print("other queues: %d kernels, %.2f ms" % (len(oth), sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in oth) / 1e6))
 PY
 rm -rf $O/tr
