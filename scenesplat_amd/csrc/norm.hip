@@ -178,7 +178,10 @@ extern "C" int ss_add_layernorm_fwd(const void* x, int x_dtype, const void* y, i
 }
 
 extern "C" int ss_add_layernorm_bwd_blocks(int64_t n) {
-  int64_t b = (n + (LN_THREADS / 64) * 8 - 1) / ((LN_THREADS / 64) * 8);   // >= 8 rows per wave
+  // rows per wave: a wave walks its rows one after the other (each a dependent load -> reduce -> store chain of 1-2 us), so the
+  // pooled levels (1,600 / 6,400 rows, launches of 13-17 us) get 2 rows per wave; large levels are capped at 1,024 workgroups anyway
+  const int rows_per_wave = n >= 32768 ? 8 : 2;
+  int64_t b = (n + (LN_THREADS / 64) * rows_per_wave - 1) / ((LN_THREADS / 64) * rows_per_wave);
   if (b > 1024) b = 1024;
   if (b < 1) b = 1;
   return (int)b;

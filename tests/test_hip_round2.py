@@ -172,7 +172,10 @@ def test_chunked_forward_training_bf16_runs_several_forwards_before_one_backward
                 sub["offset"] = torch.tensor([e - s], device="cuda"); sub["epoch_progress"] = None
                 losses.append(model(sub)["loss"])
         ref = torch.stack(losses).mean()
-    assert abs(out["loss"].item() - ref.item()) < 1e-5 * abs(ref.item()) + 1e-6
+    # not bit-equal by construction: the second pass starts from the BatchNorm running means the first pass left behind, and those
+    # condition the one-pass batch variance (sums of x - running_mean); measured 2e-6 .. 2e-5 relative depending on the reduction
+    # tree of the statistics.  A stale or overwritten weight shadow shows up at 1e-2.
+    assert abs(out["loss"].item() - ref.item()) < 1e-4 * abs(ref.item()) + 1e-6
 
 
 def test_bf16_shadows_follow_the_parameters():
