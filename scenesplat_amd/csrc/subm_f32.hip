@@ -5,9 +5,10 @@
 // (it propagates through all 22 blocks), so rounds 1-2 ran that stage on hi/lo-split bf16 operands
 // ("bf16x3": 3x the products on 128-column tiles for 32 output channels, 1.6 ms per step, bound by the neighbour gather).
 // Here: v_mfma_f32_32x32x2_f32 -- fp32 in, fp32 accumulate, bit-for-bit a k-ordered fmaf chain -- on 32-site x 32-channel tiles.
-// The stage is 11.4 GFLOP per pass: at the fp32 matrix rate (1/16 of bf16) that is ~0.1 ms of pipe time over the chip; what
-// matters is the gather, so the kernels are built for occupancy (one 32- or 64-site tile per WAVE, no workgroup barrier, 4 waves
-// per SIMD), not for tile reuse.
+// The stage is 11.4 GFLOP per pass: at the fp32 matrix rate (157 TFLOP/s, 1/16 of bf16) that is 12-16 us of pipe time per conv
+// over the chip; what matters is the gather, so the kernels are built for occupancy (one 32-site tile per WAVE, no workgroup
+// barrier, 3 waves per SIMD), not for tile reuse.  Measured (scripts/f32conv_probe.py, 102,400 sites): 32 -> 32, k = 3 forward
+// 46 us, weight gradient 54-65 us; stem 11 -> 32, k = 5 forward 62 us, weight gradient 200 us.
 //
 //   forward / dgrad   out[s][co] = bias[co] + sum_tap sum_ci in[nbr[tap][s]][ci] * W[co][tap][ci]     (dgrad: mirrored weights)
 //   weight gradient   dW[co][tap][ci] += sum_s g[s][co] * in[nbr[tap][s]][ci]       (fp32 atomics, one flush per (tap, share))
