@@ -366,11 +366,21 @@ class PlanAhead:
 
     def _run(self):
         import queue
+        import time
         try:
             if self._device is not None:
                 torch.cuda.set_device(self._device)
             while not self._stop:
-                plan = self._build()
+                try:
+                    plan = self._build()
+                except RuntimeError as e:
+                    # torch's synchronisation detector is PROCESS-wide: while another thread has it armed (steady_state.py runs
+                    # one eager step under set_sync_debug_mode("error") before it captures) the build's host round trips raise
+                    # here.  Not a failure of the build: wait for the window to pass and build again.
+                    if "synchronizing" in str(e) and not self._stop:
+                        time.sleep(0.005)
+                        continue
+                    raise
                 while not self._stop:
                     try:
                         self._q.put(plan, timeout=0.05)

@@ -267,6 +267,24 @@ def test_plan_ahead_thread_hands_over_plans_equal_to_direct_builds():
         ahead.close()
         assert not ahead._t.is_alive()
 
+        # torch's sync detector is process-wide: a build that runs while another thread has it armed (steady_state's checked eager
+        # step) raises inside the plan thread -- which must wait the window out, not die
+        calls = []
+
+        def build():
+            calls.append(1)
+            return model.prepare_plan(inp, perms=perms, stream=side)
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            armed = PlanAhead(build, depth=1)
+            import time
+            time.sleep(0.2)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        plan = armed.get()
+        assert plan.signature() == direct.signature() and len(calls) >= 2          # the first build(s) hit the armed window
+        armed.close()
+
         def boom():
             raise ValueError("no batch")
         bad = PlanAhead(boom, depth=1)
