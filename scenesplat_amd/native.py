@@ -19,6 +19,7 @@ ORDER_IDS = {"z": 0, "z-trans": 1, "hilbert": 2, "hilbert-trans": 3}
 
 _GROUP_WIDE_SHARES = os.environ.get("SS_WGRAD_GROUP_WIDE", "1") != "0"   # 0: plan every problem of a group as if it had the chip to itself (diagnostic A/B)
 _GROUP_KEEP = []      # (event, pinned sources, device copies) of grouped launches whose upload may still be in flight
+_GROUP_LOCK = __import__("threading").Lock()
 
 
 class DescriptorPool:
@@ -74,14 +75,15 @@ def _upload_descriptors(desc, starts, dev):
     # the pinned sources must outlive their asynchronous copies: each upload is kept until an event recorded behind it has passed
     # (a thread whose stream is capturing must not query events: it only appends)
     ev = None
-    if not torch.cuda.is_current_stream_capturing():
-        ev = torch.cuda.Event(); ev.record()
-        while _GROUP_KEEP and _GROUP_KEEP[0][0] is not None and _GROUP_KEEP[0][0].query():
+    with _GROUP_LOCK:                         # (grouped launches may come from more than one host thread)
+        if not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event(); ev.record()
+            while _GROUP_KEEP and _GROUP_KEEP[0][0] is not None and _GROUP_KEEP[0][0].query():
+                _GROUP_KEEP.pop(0)
+        _GROUP_KEEP.append((ev, d_host, s_host, d_dev, s_dev))
+        if len(_GROUP_KEEP) > 4096:           # (never reached in practice: a stalled stream would have to hold thousands of launches)
+            _GROUP_KEEP[0][0].synchronize() if _GROUP_KEEP[0][0] is not None else None
             _GROUP_KEEP.pop(0)
-    _GROUP_KEEP.append((ev, d_host, s_host, d_dev, s_dev))
-    if len(_GROUP_KEEP) > 4096:               # (never reached in practice: a stalled stream would have to hold thousands of launches)
-        _GROUP_KEEP[0][0].synchronize() if _GROUP_KEEP[0][0] is not None else None
-        _GROUP_KEEP.pop(0)
     return d_dev, s_dev
 
 
