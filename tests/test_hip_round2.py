@@ -406,7 +406,22 @@ def _rccl_worker(port, q):
             opt.step()
         torch.cuda.synchronize()
         out[wrapped] = torch.cat([p.detach().float().flatten() for p in model.parameters()]).cpu().numpy()
-    q.put((out[False], out[True], dist.get_backend()))
+    # the packed stage exchange (grad_exchange.StageGradExchange._reduce_whole) asks RCCL for ReduceOp.AVG: the op must exist on this
+    # stack and average a large fp32 buffer exactly on one rank; then the exchange itself in its packed form (force: one-rank rehearsal)
+    from scenesplat_amd.grad_exchange import StageGradExchange
+    x = torch.randn(1 << 22, device="cuda"); y = x.clone()
+    dist.all_reduce(y, op=dist.ReduceOp.AVG)
+    avg_ok = bool(torch.equal(x, y))
+    ex = StageGradExchange(model, force=True, hooks=False)
+    model.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = model(d)["loss"]
+    loss.backward()
+    ref = {n_: p.grad.clone() for n_, p in model.named_parameters() if p.grad is not None}
+    ex.pack(); ex.reduce()
+    torch.cuda.synchronize()
+    packed_ok = all(torch.equal(p.grad, ref[n_]) for n_, p in model.named_parameters() if n_ in ref) and len(ex.whole) == 1
+    q.put((out[False], out[True], dist.get_backend(), avg_ok, packed_ok))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -422,9 +437,10 @@ def test_ddp_over_rccl_single_rank_matches_the_unwrapped_model():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
     p.start()
-    plain, ddp, backend = q.get(timeout=500)
+    plain, ddp, backend, avg_ok, packed_ok = q.get(timeout=500)
     p.join(60)
     assert p.exitcode == 0 and backend == "nccl"
+    assert avg_ok and packed_ok            # RCCL implements ReduceOp.AVG; pack() + reduce() leave every gradient in its slot, unchanged on one rank
     assert np.isfinite(ddp).all()
     assert np.linalg.norm(ddp - plain) <= 2e-2 * np.linalg.norm(plain)
 
