@@ -9,7 +9,8 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 #ifndef SC_WAVES
-#define SC_WAVES 8     // 8 waves x 32 rows: the text tile of a K step is staged once per 256 Gaussians
+#define SC_WAVES 4     // 4 waves x 32 rows, two workgroups per CU (one stages while the other multiplies): 0.401 ms per 1 M x 768 x 160 scan
+                       // against 0.448 ms with 8 waves x 32 rows and one workgroup per CU (sustained, scripts/power_probe.py scan)
 #endif
 #define SC_THREADS (64 * SC_WAVES)
 #define SC_BM (32 * SC_WAVES)      // rows per workgroup
