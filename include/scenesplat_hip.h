@@ -93,6 +93,10 @@ int ss_cast_bf16_group_elems_per_workgroup(void);
  * key = the 64-bit seed read from DEVICE memory (so a captured launch draws fresh masks per replay). */
 int ss_row_keep_scales(const int64_t* seed, const float* keep, float* out, int64_t n, ss_stream_t stream);
 
+/* ---- exact-erf GELU of the MLP (ptv3:225-248, nn.GELU()) on flat arrays ---------------------------------------
+ * dy == NULL: out = gelu(x); else out = dy * gelu'(x).  dtype SS_F32 | SS_BF16 (math in fp32, one rounding); 16-byte aligned. */
+int ss_gelu(const void* x, const void* dy, void* out, int64_t numel, int dtype, ss_stream_t stream);
+
 /* ---- runtime queries -------------------------------------------------------------------- */
 /* 0 = the stream is not capturing, 1 = capturing, 2 = its capture was invalidated (abandon it: never end it), < 0 = query failed */
 int ss_stream_capture_status(ss_stream_t stream);

@@ -36,6 +36,7 @@ PROTOTYPES = {
     "ss_window_attn_bwd_workspace_bytes": (c_sz, [c_i64, c_i64, c_i, c_i, c_i]),
     "ss_window_attn_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i64, c_i64, c_i, c_i, c_f, c_i, c_i,
                                  c_p, c_p, c_sz, c_p]),
+    "ss_gelu": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p]),
     "ss_row_keep_scales": (c_i, [c_p, c_p, c_p, c_i64, c_p]),
     "ss_stream_capture_status": (c_i, [c_p]),
     "ss_stream_capture_id": (ctypes.c_ulonglong, [c_p]),

@@ -729,3 +729,75 @@ extern "C" int ss_bn_bwd_finish(const float* part, int nblocks, int channels, in
   SS_LAUNCH(k_bn_bwd_finish, dim3(ss_div_up(channels, 32)), dim3(BNF_THREADS), 0, stream, part, nblocks, channels, (float)n, sums, coef);
   return SS_OK;
 }
+
+
+// =====================================================================================
+// Stand-alone exact-erf GELU of the MLP (ptv3:225-248: Linear -> nn.GELU() -> Linear), forward and backward, on (n, 4C) bf16 or
+// fp32 tensors as flat arrays: y = 0.5 x (1 + erf(x / sqrt 2)), dx = dy (Phi(x) + x phi(x)) -- the fp32 formulas torch evaluates
+// (at::native GeluCUDAKernelImpl / GeluBackwardCUDAKernelImpl, approximate = 'none'), one rounding to the storage type.
+// HBM-bound: 16-byte lanes, eight (bf16) or four (fp32) elements per thread.  Why it is not an epilogue of the fc1 GEMM: DESIGN.md
+// section 4 ("Why the exact-erf GELU is not in a GEMM epilogue").
+// =====================================================================================
+__device__ __forceinline__ float dgelu_exact(float z) {
+  return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * expf(-0.5f * z * z);
+}
+__device__ __forceinline__ void bf8_unpack(const uint4& u, float (&v)[8]) {
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u); v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+  v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u); v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 bf8_pack(const float (&v)[8]) {
+  uint4 o; o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+  return o;
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+k_gelu_bf16(const unsigned short* __restrict__ x, const unsigned short* __restrict__ dy, unsigned short* __restrict__ out, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i + 8 <= n) {
+    float a[8], g[8], r[8];
+    bf8_unpack(*reinterpret_cast<const uint4*>(x + i), a);
+    if (BWD) bf8_unpack(*reinterpret_cast<const uint4*>(dy + i), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = BWD ? g[e] * dgelu_exact(a[e]) : gelu_f(a[e]);
+    *reinterpret_cast<uint4*>(out + i) = bf8_pack(r);
+  } else {
+    for (int64_t k = i; k < n; ++k) {
+      const float a = bf16_to_f32(x[k]);
+      out[k] = f32_to_bf16(BWD ? bf16_to_f32(dy[k]) * dgelu_exact(a) : gelu_f(a));
+    }
+  }
+}
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+k_gelu_f32(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 4 <= n) {
+    const float4 a = *reinterpret_cast<const float4*>(x + i);
+    float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (BWD) g = *reinterpret_cast<const float4*>(dy + i);
+    float4 r;
+    r.x = BWD ? g.x * dgelu_exact(a.x) : gelu_f(a.x); r.y = BWD ? g.y * dgelu_exact(a.y) : gelu_f(a.y);
+    r.z = BWD ? g.z * dgelu_exact(a.z) : gelu_f(a.z); r.w = BWD ? g.w * dgelu_exact(a.w) : gelu_f(a.w);
+    *reinterpret_cast<float4*>(out + i) = r;
+  } else {
+    for (int64_t k = i; k < n; ++k) out[k] = BWD ? dy[k] * dgelu_exact(x[k]) : gelu_f(x[k]);
+  }
+}
+
+// x, dy (NULL = forward), out: flat arrays of `numel` elements of `dtype` (SS_F32 | SS_BF16), 16-byte aligned bases
+extern "C" int ss_gelu(const void* x, const void* dy, void* out, int64_t numel, int dtype, hipStream_t stream) {
+  if (numel < 0 || (dtype != SS_F32 && dtype != SS_BF16)) return SS_ERR_ARG;
+  if (numel == 0) return SS_OK;
+  if (!x || !out || (((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy) & 15)) return SS_ERR_ARG;
+  const int per = dtype == SS_BF16 ? 8 : 4;
+  dim3 g((unsigned)ss_div_up(ss_div_up(numel, per), 256)), b(256);
+  if (dtype == SS_BF16) {
+    if (dy) SS_LAUNCH((k_gelu_bf16<true>), g, b, 0, stream, (const unsigned short*)x, (const unsigned short*)dy, (unsigned short*)out, numel);
+    else SS_LAUNCH((k_gelu_bf16<false>), g, b, 0, stream, (const unsigned short*)x, (const unsigned short*)nullptr, (unsigned short*)out, numel);
+  } else {
+    if (dy) SS_LAUNCH((k_gelu_f32<true>), g, b, 0, stream, (const float*)x, (const float*)dy, (float*)out, numel);
+    else SS_LAUNCH((k_gelu_f32<false>), g, b, 0, stream, (const float*)x, (const float*)nullptr, (float*)out, numel);
+  }
+  return SS_OK;
+}

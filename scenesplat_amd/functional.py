@@ -352,6 +352,31 @@ def subm_conv3d(feat, weight, bias, nbr, has_dup=False, compute_dtype=torch.floa
     return _SubMConv3d.apply(feat, weight, bias, nbr, has_dup, compute_dtype)
 
 
+class _Gelu(torch.autograd.Function):
+    """nn.GELU() (exact erf) of the MLP (ptv3:225-248) on the HIP kernel pair of csrc/norm.hip: the fp32 formulas torch evaluates,
+    one rounding to the storage type."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return nv.gelu(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return nv.gelu(x, dy.contiguous().to(x.dtype))
+
+
+GELU_HIP = os.environ.get("SS_GELU_HIP", "1") != "0"       # 0: torch's elementwise GELU kernels (A/B: scripts/ab_step.py gelu)
+
+
+def gelu(x):
+    if GELU_HIP and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+        return _Gelu.apply(x)
+    return torch.nn.functional.gelu(x)
+
+
 def lang_head_release():
     """Drop the remembered sums (and with them the autograd graph they hold) once the criteria have run."""
     _HEAD_CACHE.clear()

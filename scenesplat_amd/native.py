@@ -944,6 +944,18 @@ def stream_capture_status(stream=None):
     return int(lib().ss_stream_capture_status(ctypes.c_void_p(st.cuda_stream)))
 
 
+def gelu(x, dy=None):
+    """Exact-erf GELU on the HIP kernel: gelu(x), or dy * gelu'(x) when dy is given.  x (any shape) bf16 | f32, contiguous."""
+    _req(x, None, "x")
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"gelu: float32 / bfloat16 only, got {x.dtype}")
+    if dy is not None:
+        _req(dy, x.dtype, "dy", x.shape)
+    out = torch.empty_like(x)
+    check(lib().ss_gelu(_p(x), _p(dy), _p(out), x.numel(), dtype_code(x), _stream()), "ss_gelu")
+    return out
+
+
 def row_keep_scales(keep, seed=None):
     """keep (n) f32 in (0, 1] -> (n) f32 of Bernoulli(keep) / keep, one Philox draw per row.  seed: (1,) int64 DEVICE tensor; None draws
     it from torch's generator of the device (graph-safe: a captured call gets a fresh seed on every replay)."""

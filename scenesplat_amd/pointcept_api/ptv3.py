@@ -140,7 +140,10 @@ class MLP(nn.Module):
         self.fc2 = nn.Linear(hidden_channels, out_channels)
 
     def forward(self, x):
-        return _lin(self.fc2, self.act(_lin(self.fc1, x)))
+        h = _lin(self.fc1, x)
+        # nn.GELU() with the exact erf form runs on the HIP kernel pair (csrc/norm.hip); any other activation stays the module's own
+        h = SF.gelu(h) if type(self.act) is nn.GELU and getattr(self.act, "approximate", "none") == "none" else self.act(h)
+        return _lin(self.fc2, h)
 
 
 class Block(PointModule):

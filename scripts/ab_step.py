@@ -54,6 +54,8 @@ def setter(on):
         SF.CONV_F32_MFMA = on
     elif which == "conv_walk":
         SF.CONV_WALK_RULEBOOK = on
+    elif which == "gelu":
+        SF.GELU_HIP = on
     elif which == "mask_small":
         import scenesplat_amd.plan as P
         P.CONV_MASK_MIN_SITES = 4096 if on else 16384

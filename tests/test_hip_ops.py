@@ -597,3 +597,32 @@ def test_row_keep_scales_are_bernoulli_over_keep_and_follow_the_seed():
     e = nv.row_keep_scales(keep)
     assert not torch.equal(d, e)
     assert nv.row_keep_scales(keep[:0]).numel() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gelu_kernels_match_the_exact_erf_form(dtype):
+    """nn.GELU() of the MLP (ptv3:225-248): forward and backward of the HIP kernel pair against torch's fp32 CPU evaluation of the same
+    operands (the oracle's activation), rounded once to the storage type: at most one unit in the last place of that type apart, and
+    through the autograd Function incl. a ragged tail and extreme arguments."""
+    from scenesplat_amd import functional as SF
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3001, 77, generator=g) * 3.0
+    x.view(-1)[:8] = torch.tensor([0.0, -0.0, 1e-8, -1e-8, 12.0, -12.0, 40.0, -40.0])
+    dy = torch.randn(3001, 77, generator=g)
+    xs, dys = x.to(dtype), dy.to(dtype)
+    xr = xs.float().clone().requires_grad_(True)
+    yr = torch.nn.functional.gelu(xr)
+    yr.backward(dys.float())
+    xg = xs.detach().cuda().requires_grad_(True)
+    y = SF.gelu(xg)
+    assert type(y.grad_fn).__name__ == "_GeluBackward" and y.dtype == dtype
+    y.backward(dys.cuda())
+    # one unit in the last place of the storage type (relative 2^-7 for bf16); fp32: erff of the device library and the host's differ by
+    # a few fp32 ulps of a value near 1, which is an ABSOLUTE error of ~1e-6 where 1 + erf cancels (x < -3)
+    eps, atol = (2.0 ** -7, 1e-5) if dtype == torch.bfloat16 else (2.0 ** -18, 4e-6)
+    for got, ref in ((y, yr), (xg.grad, xr.grad)):
+        got, ref = got.detach().float().cpu(), ref.detach()
+        assert torch.isfinite(got).all()
+        err = (got - ref.to(dtype).float()).abs()
+        worst = float((err - eps * ref.abs()).max())
+        assert worst <= atol, worst
