@@ -413,7 +413,7 @@ class PointTransformerV3(PointModule):
                 if isinstance(m, nn.Linear):
                     params += [m.weight, m.bias]
                 elif isinstance(m, SubMConv3d):
-                    params.append(m.weight)
+                    params += [m.weight, m.bias]         # (the bias feeds the small levels' im2col GEMM as a bf16 operand)
             src, dst = SF.register_shadows(params)
             # wide Linear layers of the two finest levels: a transposed copy for the NT form of their dgrad GEMM
             wide = []

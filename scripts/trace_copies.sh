@@ -4,7 +4,7 @@ cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 O=gpurun_out/r3c
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python bench.py --steps 4 --warmup 2 --no-pmc --no-secondary --no-cpu-baseline > $O/run.log 2>&1
+SS_BENCH_CALIBRATE=0 rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python bench.py --steps 4 --warmup 2 --no-pmc --no-secondary --no-cpu-baseline > $O/run.log 2>&1
 python - <<'PY'
 import csv, glob, os, collections
 O = "gpurun_out/r3c"
