@@ -691,6 +691,31 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+class _LinearGelu(torch.autograd.Function):
+    """fc1 + nn.GELU() of the MLP (ptv3:225-248) as ONE autograd node: library GEMM, then the exact-erf GELU on the HIP kernel
+    (csrc/norm.hip); backward = gelu' on the HIP kernel, then the Linear's own backward (_linear_backward).  One node instead of two: an
+    eager step crosses Python once less per block and direction (a Python autograd Function costs ~50 us of host time per apply +
+    backward pair; the eager variable-size line is host-bound)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w16, b16, stage, w16t=None):
+        u = torch.nn.functional.linear(x, w16, b16)
+        ctx.save_for_backward(x, w16 if w16t is None else w16t, u)
+        ctx.meta = (weight.dtype, bias is not None)
+        ctx.dgrad_nt = w16t is not None
+        ctx.stage = stage
+        return nv.gelu(u)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w16, u = ctx.saved_tensors
+        w_dtype, has_bias = ctx.meta
+        du = nv.gelu(u, dy.contiguous())
+        dx, dw, db = _linear_backward(x, w16, ctx.dgrad_nt, w_dtype, has_bias, ctx.stage, du, ctx.needs_input_grad[0],
+                                      ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return dx, dw, db, None, None, None, None
+
+
 def _linear_backward(x, w16, dgrad_nt, w_dtype, has_bias, stage, dy, need_x, need_w, need_b):
     """dx, dW, db of y = x @ W.T + b (the backward of _Linear and of the fused qkv + attention function)."""
     dx = dw = db = None
@@ -735,6 +760,20 @@ def linear(x, weight, bias=None):
                                  _STAGE["cur"], bf16_t_of(weight))
         return _Linear.apply(x.to(torch.bfloat16).contiguous(), weight, bias, bf16_of(weight), bf16_of(bias), None, bf16_t_of(weight))
     return torch.nn.functional.linear(x, weight, bias)
+
+
+def linear_gelu(x, weight, bias=None):
+    """gelu(linear(x)) with the exact erf form; under CUDA bf16 autocast on 2-D input one autograd node (_LinearGelu)."""
+    if GELU_HIP and x.is_cuda and x.dim() == 2 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16 \
+            and weight.dtype == torch.float32 and torch.is_grad_enabled():
+        route = _STAGE["route"]
+        wr = route.get(id(weight)) if route else None
+        if wr is not None:
+            br = route.get(id(bias)) if bias is not None else None
+            return _LinearGelu.apply(x.to(torch.bfloat16).contiguous(), wr, br if br is not None else bias, bf16_of(weight), bf16_of(bias),
+                                     _STAGE["cur"], bf16_t_of(weight))
+        return _LinearGelu.apply(x.to(torch.bfloat16).contiguous(), weight, bias, bf16_of(weight), bf16_of(bias), None, bf16_t_of(weight))
+    return gelu(linear(x, weight, bias))
 
 
 class _QkvWindowAttentionHM(torch.autograd.Function):

@@ -140,9 +140,12 @@ class MLP(nn.Module):
         self.fc2 = nn.Linear(hidden_channels, out_channels)
 
     def forward(self, x):
-        h = _lin(self.fc1, x)
-        # nn.GELU() with the exact erf form runs on the HIP kernel pair (csrc/norm.hip); any other activation stays the module's own
-        h = SF.gelu(h) if type(self.act) is nn.GELU and getattr(self.act, "approximate", "none") == "none" else self.act(h)
+        # nn.GELU() with the exact erf form runs on the HIP kernel pair (csrc/norm.hip), in one autograd node with fc1; any other
+        # activation stays the module's own
+        if type(self.act) is nn.GELU and getattr(self.act, "approximate", "none") == "none":
+            h = SF.linear_gelu(x, self.fc1.weight, self.fc1.bias)
+        else:
+            h = self.act(_lin(self.fc1, x))
         return _lin(self.fc2, h)
 
 
