@@ -1,0 +1,58 @@
+"""Host-side logic that needs no GPU: the plan-ahead thread (scenesplat_amd/plan.py:PlanAhead) and the stage labels of the gradient
+exchange (scenesplat_amd/grad_exchange.py:default_stage_of).  (The GPU behaviour of both is covered in tests/test_hip_round2.py and
+tests/test_engine_dist.py.)"""
+import threading
+import time
+
+import pytest
+
+
+def test_plan_ahead_hands_over_in_order_bounds_its_queue_and_stops():
+    from scenesplat_amd.plan import PlanAhead
+    built = []
+
+    def build():
+        built.append(len(built))
+        return ("plan", built[-1])
+    ahead = PlanAhead(build, depth=2, device=None)
+    got = [ahead.get() for _ in range(5)]
+    assert got == [("plan", i) for i in range(5)]                 # in build order
+    time.sleep(0.2)
+    assert len(built) <= 5 + 2 + 1                                 # at most `depth` queued + one being offered
+    ahead.close()
+    assert not ahead._t.is_alive()
+    n = len(built)
+    time.sleep(0.1)
+    assert len(built) == n                                         # nothing is built after close()
+
+
+def test_plan_ahead_retries_builds_that_hit_the_armed_sync_detector_and_surfaces_real_errors():
+    from scenesplat_amd.plan import PlanAhead
+    calls = []
+
+    def flaky():
+        calls.append(1)
+        if len(calls) < 3:
+            raise RuntimeError("called a synchronizing HIP operation")         # torch's process-wide detector, armed by another thread
+        return "plan"
+    ahead = PlanAhead(flaky, depth=1, device=None)
+    assert ahead.get() == "plan" and len(calls) >= 3
+    ahead.close()
+
+    def broken():
+        raise ValueError("no batch")
+    bad = PlanAhead(broken, depth=1, device=None)
+    with pytest.raises(RuntimeError, match="plan build thread failed") as ei:
+        bad.get()
+    assert isinstance(ei.value.__cause__, ValueError)
+    bad.close()
+    assert threading.active_count() < 20
+
+
+def test_stage_labels_follow_the_backward_order_of_pt_v3m1_names():
+    from scenesplat_amd.grad_exchange import default_stage_of
+    assert default_stage_of("backbone.dec.dec0.block1.mlp.0.fc1.weight") == "dec.dec0"
+    assert default_stage_of("module.backbone.enc.enc3.down.proj.weight") == "enc.enc3"
+    assert default_stage_of("backbone.embedding.stem.conv.weight") == "embedding"
+    assert default_stage_of("enc.enc0.block0.cpe.0.weight") == "enc.enc0"
+    assert default_stage_of("criteria.0.temperature") == "other"
