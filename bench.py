@@ -286,11 +286,12 @@ def secondary_lines(log, steps=3):
         # two untimed steps at the SphereCrop cap (2 x 192,000) first: the caching allocator's pools are then as large as any later
         # batch needs -- a run that has seen its largest batch, as any training run has after a few hundred steps.  (Without this the
         # timed steps paid hipMalloc / hipFree storms whenever a batch outgrew the warm-up ones: 93-160 ms per step across boxes.)
-        sizes = [[192000, 192000]] * 2 + [[rng.randrange(60000, 192001) for _ in range(2)] for _ in range(steps)]
+        sizes = [[192000, 192000]] * 2 + [[rng.randrange(60000, 192001) for _ in range(2)] for _ in range(4 + steps)]
         batches = [batch_of(sz) for sz in sizes]
+        n_warm = len(batches) - steps                  # 2 steps at the cap + 4 of random size, all untimed; then `steps` new shapes, timed
         tot = 0
         for i, b in enumerate(batches):
-            if i == 2:
+            if i == n_warm:
                 # (as the primary line does: one full collection, then no generation-2 scan inside the three timed steps -- an eager
                 # step allocates ~10^5 Python objects and an untimely full collection costs ~50 ms)
                 gc.collect(); gc.disable()
