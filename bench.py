@@ -76,6 +76,9 @@ def parse():
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay forward+backward as a hipGraph once the plan shape repeats (auto: single-rank runs)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline traffic = null)")
+    ap.add_argument("--power", action="store_true", help="also run every matrix-bound probe back to back for 2.5 s with rocm-smi polled beside it (adds "
+                    "`sustained` {ms, socket_power_w, sclk_mhz} to its roofline object; off by default: thousands of extra launches would "
+                    "dominate the per-kernel averages of a rocprofv3 trace of this command)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-3 and fp32-conv secondary lines")
     return ap.parse_args()
 
@@ -158,8 +161,10 @@ def power_limited_peak(log):
         return None
 
 
-def roofline_lines(log, want_pmc):
-    """roofline objects of the bench line: every probe timed with HIP events in THIS process, PMC traffic from child passes."""
+def roofline_lines(log, want_pmc, want_power=False):
+    """roofline objects of the bench line: every probe timed with HIP events in THIS process, PMC traffic from child passes.  The
+    matrix-bound probes are also run back to back for 2.5 s with rocm-smi polled beside them ("sustained": what the chip holds under
+    that kernel alone -- these kernels run the package at its power cap)."""
     rp = _probes_module()
     probes = rp.build()
     traffic = pmc_traffic(log) if want_pmc else {}
@@ -171,6 +176,20 @@ def roofline_lines(log, want_pmc):
         log("probe %-10s %.3f ms  %.0f %s (%.1f %% of peak)%s" % (p["name"], ms, res[p["name"]]["achieved"], res[p["name"]]["unit"],
                                                                   100 * res[p["name"]]["frac"],
                                                                   "  traffic %.0f MB" % (sum(tr) / 1e6) if tr else ""))
+    if want_power:
+        for p in probes:
+            if p["bound"] != "mfma":
+                continue
+            try:
+                sus = rp.sustained_probe(p)
+            except Exception as e:  # noqa: BLE001 -- diagnostic only
+                log("sustained probe %s skipped: %r" % (p["name"], e)); sus = None
+            if sus:
+                sus["achieved"] = p["flops"] / (sus["ms"] * 1e-3) / 1e12
+                sus["frac"] = sus["achieved"] / res[p["name"]]["peak"]
+                res[p["name"]]["sustained"] = sus
+                log("sustained %-10s %.3f ms over %d launches = %.0f TFLOP/s (%.1f %%) at %.0f W, sclk %.0f MHz" % (
+                    p["name"], sus["ms"], sus["launches"], sus["achieved"], 100 * sus["frac"], sus["socket_power_w"], sus["sclk_mhz"]))
     return res
 
 
@@ -588,7 +607,7 @@ def main():
             state.clear()
             net = model = None                                 # (cells of step(): releases the model and its plan)
             gc.collect(); torch.cuda.empty_cache()
-            rl = roofline_lines(log, not args.no_pmc)
+            rl = roofline_lines(log, not args.no_pmc, args.power)
             plp = power_limited_peak(log)
             for ent in rl.values():
                 if ent.get("bound") == "mfma" and plp:

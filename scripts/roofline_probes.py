@@ -119,6 +119,48 @@ def time_probe(p, iters=5, warmup=2):
     return s.elapsed_time(e) / iters
 
 
+def sustained_probe(p, secs=2.5):
+    """Launch the probe back to back for `secs` seconds while a thread polls rocm-smi: -> dict(ms, socket_power_w, sclk_mhz, launches) or
+    None when rocm-smi is not there.  What the chip holds under THIS kernel alone (the 1,400 W cap pulls the clock of the matrix kernels)."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    import time
+    if shutil.which("rocm-smi") is None:
+        return None
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                pw = re.search(r"Power \(W\): ([0-9.]+)", out); sc = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
+                if pw and sc:
+                    samples.append((time.time(), float(pw.group(1)), int(sc.group(1))))
+            except Exception:  # noqa: BLE001 -- a missing or slow tool must not take the bench line down
+                return
+            time.sleep(0.3)
+    th = threading.Thread(target=poll, daemon=True); th.start()
+    for _ in range(5):
+        p["run"]()
+    torch.cuda.synchronize()
+    t0 = time.time(); n = 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    while time.time() - t0 < secs:
+        for _ in range(25):
+            p["run"]()
+        n += 25
+        torch.cuda.synchronize()
+    e1.record(); torch.cuda.synchronize()
+    stop.set(); th.join(timeout=12)
+    mid = [s_ for s_ in samples if t0 + 0.8 < s_[0] < t0 + secs]
+    if not mid:
+        return None
+    return dict(ms=e0.elapsed_time(e1) / n, launches=n, socket_power_w=sum(s_[1] for s_ in mid) / len(mid), sclk_mhz=sum(s_[2] for s_ in mid) / len(mid))
+
+
 def roofline_entry(p, ms, traffic=None):
     if p["bound"] == "mfma":
         ach = p["flops"] / (ms * 1e-3) / 1e12
