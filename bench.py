@@ -316,38 +316,59 @@ def secondary_lines(log, steps=3):
         big = room_chunk(352, 3, lang_dim=0)                     # 352^2 + 2 * 352 * 99 = 193,600 unique voxels to crop from
         gcb, fb = big["grid_coord"], big["feat"]
 
-        def batch_of(sizes):
+        def batch_of(sizes, merge=False):
             parts, off = [], []
             for j, m in enumerate(sizes):
                 sel = torch.randperm(len(gcb), generator=torch.Generator().manual_seed(100 * j + m))[:m]
                 parts.append((gcb[sel], fb[sel])); off.append(m)
+            # merge: Mix3D (datasets/utils.py:43-47, mix_prob = 0.8 in every language config) -- the two samples become ONE batch
+            # element; both are crops of the same room, so ~(m / 193,600)^2 of its voxels hold two Gaussians (duplicate voxels)
             return dict(grid_coord=torch.cat([p[0] for p in parts]).cuda(), feat=torch.cat([p[1] for p in parts]).cuda(),
-                        offset=torch.tensor(off).cumsum(0).cuda())
+                        offset=(torch.tensor([sum(off)]) if merge else torch.tensor(off).cumsum(0)).cuda())
         # two untimed steps at the SphereCrop cap (2 x 192,000) first: the caching allocator's pools are then as large as any later
         # batch needs -- a run that has seen its largest batch, as any training run has after a few hundred steps.  (Without this the
         # timed steps paid hipMalloc / hipFree storms whenever a batch outgrew the warm-up ones: 93-160 ms per step across boxes.)
         sizes = [[192000, 192000]] * 2 + [[rng.randrange(60000, 192001) for _ in range(2)] for _ in range(4 + steps)]
-        batches = [batch_of(sz) for sz in sizes]
-        n_warm = len(batches) - steps                  # 2 steps at the cap + 4 of random size, all untimed; then `steps` new shapes, timed
-        tot = 0
-        for i, b in enumerate(batches):
-            if i == n_warm:
-                # (as the primary line does: one full collection, then no generation-2 scan inside the three timed steps -- an eager
-                # step allocates ~10^5 Python objects and an untimely full collection costs ~50 ms)
-                gc.collect(); gc.disable()
-                torch.cuda.synchronize(); t0 = time.perf_counter(); tot = 0
-            model.zero_grad(set_to_none=True)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                o = model(dict(b))
-            torch.autograd.backward(o.feat, grad_tensors=torch.ones_like(o.feat))
-            tot += b["feat"].shape[0]
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        gc.enable()
+
+        def eager_line(merge):
+            batches = [batch_of(sz, merge) for sz in sizes]
+            n_warm = len(batches) - steps              # 2 steps at the cap + 4 of random size, all untimed; then `steps` new shapes, timed
+            tot, t0, dups = 0, 0.0, 0
+            for i, b in enumerate(batches):
+                if i == n_warm:
+                    # (as the primary line does: one full collection, then no generation-2 scan inside the three timed steps -- an eager
+                    # step allocates ~10^5 Python objects and an untimely full collection costs ~50 ms)
+                    gc.collect(); gc.disable()
+                    torch.cuda.synchronize(); t0 = time.perf_counter(); tot = 0
+                model.zero_grad(set_to_none=True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    o = model(dict(b))
+                torch.autograd.backward(o.feat, grad_tensors=torch.ones_like(o.feat))
+                tot += b["feat"].shape[0]
+                if merge and not o["plan"].levels[0].has_duplicates:
+                    raise RuntimeError("Mix3D line: a merged batch without duplicate voxels")
+            torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t0
+            gc.enable()
+            if merge:      # Gaussians that share their voxel with an earlier row, last batch (one host read, after the timed region)
+                lv0 = o["plan"].levels[0]
+                dups = int((lv0.neighbors(3)[13] != torch.arange(lv0.n, device="cuda", dtype=torch.int32)).sum())
+            del batches
+            return tot, dt_, dups
+
+        tot, dt, _ = eager_line(False)
         out["variable_size_training_b2"] = dict(metric="Gaussians/s encoder fwd+bwd, EAGER launches, 2 chunks per step of 60,000-192,000 Gaussians each (a new plan shape every step), 1 GPU",
                                                 value=tot / dt, unit="Gaussians/s", ms_per_step=dt / steps * 1e3, steps=steps,
                                                 gaussians_per_step=tot / steps, dtype="bf16")
-        del model, batches
+        gc.collect(); torch.cuda.empty_cache()
+        # ---- the Mix3D regime (round 4): the SAME batches with the two samples merged into one batch element, as point_collate_fn
+        # does in 80 % of the reference's training steps -- duplicate voxels at level 0, handled inside the MFMA conv paths
+        tot, dt, dups = eager_line(True)
+        out["mix3d_training_b2"] = dict(metric="Gaussians/s encoder fwd+bwd, EAGER launches, the variable-size batches with both samples Mix3D-merged into one batch element (duplicate voxels at level 0), 1 GPU",
+                                        value=tot / dt, unit="Gaussians/s", ms_per_step=dt / steps * 1e3, steps=steps,
+                                        gaussians_per_step=tot / steps, duplicate_rows_last_batch=dups,
+                                        vs_variable_size_training_b2=(tot / dt) / out["variable_size_training_b2"]["value"], dtype="bf16")
+        del model
         gc.collect(); torch.cuda.empty_cache()
         # ---- BASELINE config 5 end to end: 1,000,000-Gaussian region -> LangPretrainer.eval()(input, chunk_size=600000) (the call
         # form of engines/test.py:329-351 / evaluator.py:762) -> 160-label feature x text scan
@@ -436,8 +457,11 @@ def main():
         from scenesplat_amd.grad_exchange import StageGradExchange
         for t_ in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t_.data, src=0)
-        # packed form (no host callbacks inside the backward): the step stays a hipGraph replay, the all-reduces follow it
-        exchange = StageGradExchange(model, force=force_ddp, hooks=(args.graph == "off"))
+        # no host callbacks inside the backward: the step stays a hipGraph replay on every rank.  Round 4, the SPLIT form: two
+        # graphs cut where the backward leaves dec0 (52 % of the gradient bytes are final there); dec0's slice is all-reduced on the
+        # process group's stream while the second graph runs the rest of the backward, the other slice after it.  --graph off runs the
+        # same two-call backward and the same two collectives with eager launches (SS_BENCH_EXCHANGE_HOOKS=1: the round-3 hook form)
+        exchange = StageGradExchange(model, force=force_ddp, hooks=(args.graph == "off" and os.environ.get("SS_BENCH_EXCHANGE_HOOKS") == "1"))
     if args.fixture == "uniform":
         from scenesplat_amd.synthetic import uniform_chunk
         data = {k: v.to(dev) for k, v in uniform_chunk(seed=rank).items()}
@@ -459,17 +483,30 @@ def main():
 
     cot16 = cot.to(torch.bfloat16)
 
+    split = exchange is not None and not exchange._hooks and os.environ.get("SS_BENCH_EXCHANGE_SPLIT", "1") != "0"
+    cutbox = {}
+    from scenesplat_amd.pointcept_api.ptv3 import backward_tail
+
     def fwd_bwd(plan, t):
+        cut = [] if split else None
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            out = net(dict(feat=t["feat"], grid_coord=data["grid_coord"], offset=data["offset"], plan=plan))
+            out = net(dict(feat=t["feat"], grid_coord=data["grid_coord"], offset=data["offset"], plan=plan,
+                           **({"backward_cut": cut} if split else {})))
         # backward from the seeded random cotangent, fed directly as the output gradient (no loss kernels)
-        torch.autograd.backward(out.feat, grad_tensors=t["cot"])
-        if exchange is not None:
+        torch.autograd.backward(out.feat, grad_tensors=t["cot"])     # split: down to the inputs of dec0 only (the model's backward cut)
+        if split:
+            exchange.pack("early")         # dec0's gradients are final: into their slice (captured with graph 1)
+            cutbox["cut"] = cut
+        elif exchange is not None:
             if exchange._hooks:
-                exchange.finish()          # eager form: the stage all-reduces were issued by hooks during the backward
+                exchange.finish()          # hook form: the stage all-reduces were issued by hooks during the backward
             else:
-                exchange.pack()            # packed form: captured with the step; the all-reduces follow the replay (step())
+                exchange.pack()            # round-3 packed form: one all-reduce over the whole model follows the replay (step())
         return {"feat": out.feat}
+
+    def fwd_bwd_tail():
+        backward_tail(cutbox.pop("cut"))   # the rest of the backward (graph 2), while dec0's all-reduce runs on RCCL's stream
+        exchange.pack("late")
 
     # Steady state (scenesplat_amd/steady_state.py): every chunk of the room has the same plan SHAPE, so after two eager
     # steps the ~1,100 launches of forward + backward are captured in a hipGraph and later steps replay it -- the plan is
@@ -479,7 +516,8 @@ def main():
     use_graph = (args.graph == "on" or (args.graph == "auto" and (world == 1 or args.exchange == "stage"))) and not (force_ddp and args.exchange == "ddp") \
         and not (world > 1 and args.exchange == "ddp")
     from scenesplat_amd.steady_state import CaptureInvalidated, SteadyStateStep
-    steady = SteadyStateStep(fwd_bwd, list(model.parameters()), warmup=1, enabled=use_graph)
+    steady = SteadyStateStep(fwd_bwd, list(model.parameters()), warmup=1, enabled=use_graph,
+                             tail=fwd_bwd_tail if split else None, between=(lambda: exchange.reduce_begin("early")) if split else None)
 
     seg = {"zero": 0.0, "steady": 0.0, "reduce": 0.0, "plan": 0.0} if os.environ.get("SS_BENCH_HOST_SEGMENTS") else None
 
@@ -491,13 +529,24 @@ def main():
         try:
             steady(plan, {"feat": data["feat"], "cot": cot16})
         except CaptureInvalidated as e:
-            # the capture could not be completed (steady_state.py abandons it and switches itself to eager launches): the step is
-            # repeated eagerly and the run goes on -- a failed capture must not take a scaling run down
-            log("hipGraph capture abandoned, eager from here: %s" % e)
-            net.zero_grad(set_to_none=True)
-            steady(plan, {"feat": data["feat"], "cot": cot16})
+            # An invalidated capture cannot be ended, and this thread still owns it: the allocator keeps the capture's pool
+            # registered, device-wide synchronisation and empty_cache() are refused from here on.  This PROCESS is done.  One rank:
+            # a FRESH child process repeats the run with --graph off and its JSON line becomes ours (started as a child, never an
+            # exec of a process that has initialised the GPU).  More ranks: exit non-zero at once -- torchrun ends the other ranks;
+            # a hang is the one outcome that must not happen.
+            log("hipGraph capture invalidated: %s" % e)
+            if world == 1 and not force_ddp and os.environ.get("SS_BENCH_CHILD") != "1":
+                import subprocess
+                argv = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]] + ["--graph", "off"]
+                log("re-running in a fresh child process with eager launches: %s" % " ".join(argv[1:]))
+                r = subprocess.run(argv, env=dict(os.environ, SS_BENCH_CHILD="1"), stdout=subprocess.PIPE)
+                os.write(_REAL_STDOUT, r.stdout)
+                os._exit(r.returncode)
+            os._exit(3)
         t_c = time.perf_counter()
-        if exchange is not None and not exchange._hooks:
+        if split:
+            exchange.reduce_begin("late"); exchange.reduce_end()
+        elif exchange is not None and not exchange._hooks:
             exchange.reduce()
         t_d = time.perf_counter()
         # SS_BENCH_REUSE_PLAN=1 is a DIAGNOSTIC (host- vs GPU-bound?): it skips the per-step plan build and the line it
@@ -596,7 +645,9 @@ def main():
                                     + " PT-v3m1 lang-pretrain encoder (91.71M params, in=11, out=768) fwd+bwd, "
                                     "1 chunk of %d Gaussians per GPU per step, serialization included") % (n, n),
                        "gaussians_per_chunk": n, "chunks_per_gpu": 1,
-                       "parallelism": "dp%d" % world, "gradient_exchange": (args.exchange if (world > 1 or force_ddp) else "none"), "attention_kernel": "mfma" if impl == nv.ATTN_MFMA else "simt",
+                       "parallelism": "dp%d" % world,
+                       "gradient_exchange": ((args.exchange + (" (split: dec0 slice all-reduced under the rest of the backward)" if split else ""))
+                                             if (world > 1 or force_ddp) else "none"), "attention_kernel": "mfma" if impl == nv.ATTN_MFMA else "simt",
                        "execution": ((("hipGraph replay of forward+backward (%d of the %d timed steps; a plan built for every step, by the plan thread, and copied in)"
                                        % (steady.replays - replays_before, args.steps)) if steady.replays > replays_before else "eager launches")
                                      + ("" if calib is None else "; chosen by an untimed calibration in this process: replay %.2f vs eager %.2f ms/step" % (calib["replay"], calib["eager"])))},

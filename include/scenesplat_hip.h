@@ -210,6 +210,11 @@ int ss_subm_conv_wgrad(const void* in, const void* dout, const int32_t* nbr, con
 int ss_subm_f32_ok(int cin_padded, int cout);
 int ss_subm_f32_fwd(const float* in, const float* wq, const float* bias, const int32_t* nbr_walk, const int32_t* rowperm,
                     float* out, int64_t n, int cin_padded, int cout, int taps, ss_stream_t stream);
+/* dgrad of the same conv on a level with DUPLICATE voxels (Mix3D batches, pointcept/datasets/utils.py:43-47; spconv leaves their
+ * semantics open, this library resolves a voxel to its lowest row): dout_folded = ss_dup_fold_rows(dout), wq = tap-mirrored
+ * transposed weights; rows that are not the winner of their voxel receive zeros.  taps must be odd. */
+int ss_subm_f32_dgrad_dup(const float* dout_folded, const float* wq, const int32_t* nbr_walk, const int32_t* rowperm, float* din,
+                          int64_t n, int cin_padded, int cout, int taps, ss_stream_t stream);
 /* dweight (32, taps, cin) f32 ACCUMULATED into (caller zeroes it); blk_* from ss_subm_block_lists with the same rowperm */
 int ss_subm_f32_wgrad(const float* in, const float* dout, const int32_t* nbr_walk, const int32_t* rowperm,
                       const int32_t* blk_count, const int32_t* blk_list, float* dweight, int64_t n, int cin_padded,
@@ -308,6 +313,14 @@ int ss_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_dst
 int ss_scatter_rows(const void* src, const int32_t* idx, void* dst, int64_t n_src, int64_t row_bytes, ss_stream_t stream);
 int ss_gather_add_rows(const void* a, const void* b, const int32_t* idx, void* dst, int64_t n, int channels, int dtype,
                        ss_stream_t stream);
+/* Duplicate voxels: adjoint of "every site of a voxel reads the voxel's winner (lowest) row" -- the fold in front of a submanifold
+ * conv's dgrad (structure.py:104-140 / spconv pairs with Mix3D-merged batch elements).  sorted_keys (n) = the codes of one curve in
+ * sorted order, order (n) = its stable argsort (ss_argsort_i64): runs of equal keys list a voxel's rows ascending.
+ * dst[winner] = sum of src over the run (fp32 accumulate, run order), dst[every other row] = 0; src != dst; row bytes % 16 == 0. */
+int ss_dup_fold_rows(const void* src, const int64_t* sorted_keys, const int32_t* order, void* dst, int64_t n, int channels,
+                     int dtype, ss_stream_t stream);
+/* x[row] = 0 for every row that is not the winner of its voxel (in place) */
+int ss_dup_zero_rows(const int64_t* sorted_keys, const int32_t* order, void* x, int64_t n, int64_t row_bytes, ss_stream_t stream);
 int ss_segment_reduce(const void* src, const int32_t* indices, const int32_t* idx_ptr, void* out, int64_t n_seg,
                       int channels, int dtype, int mean, ss_stream_t stream);
 /* reduce = "min" / "max" of torch_scatter.segment_csr: out (n_seg,C) and arg (n_seg,C) int32 = source row attaining it

@@ -81,6 +81,9 @@ PROTOTYPES = {
     "ss_subm_conv_wgrad_walk": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "ss_subm_f32_ok": (c_i, [c_i, c_i]),
     "ss_subm_f32_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
+    "ss_subm_f32_dgrad_dup": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
+    "ss_dup_fold_rows": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p]),
+    "ss_dup_zero_rows": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_p]),
     "ss_subm_f32_wgrad": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "ss_add_layernorm_fwd": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_f, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i64, c_i, c_p]),
     "ss_add_layernorm_bwd_blocks": (c_i, [c_i64]),

@@ -531,3 +531,84 @@ extern "C" int ss_subm_weight_mirror_group(const int64_t* desc, const int32_t* w
   SS_LAUNCH(k_subm_weight_mirror_group, dim3((unsigned)total_workgroups), dim3(256), 0, stream, desc, wg_start, nprob);
   return SS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Duplicate voxels (Mix3D batches: two samples share one batch element, pointcept/datasets/utils.py:43-47).  Every site of a voxel
+// reads the voxel's WINNER row (its lowest row: what the rulebook resolves to), so the adjoint of a submanifold conv first folds the
+// gradients of all sites of a voxel onto the winner and leaves the other rows -- which nobody reads -- with a zero gradient.
+// The runs come from the plan: sorted_keys (n) = the codes of one curve in sorted order, order (n) = its STABLE argsort, so a run of
+// equal keys lists the rows of one voxel in ascending order and its first entry is the winner.  One thread per (sorted position,
+// 16-byte chunk): run heads sum their run in fp32 (in run order: deterministic), every other position writes zeros; each destination
+// row is written exactly once.
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <bool BF16>
+__global__ void k_dup_fold_rows(const uint4* __restrict__ src, const int64_t* __restrict__ keys, const int32_t* __restrict__ order,
+                                uint4* __restrict__ dst, int64_t n, int chunks) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * chunks) return;
+  const int64_t p = gid / chunks; const int c = (int)(gid - p * chunks);
+  const int64_t key = keys[p];
+  const int64_t row = order[p];
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (p == 0 || keys[p - 1] != key) {
+    v = src[row * chunks + c];
+    if (p + 1 < n && keys[p + 1] == key) {
+      float a[8];
+      if (BF16) {
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[2 * e] = __uint_as_float(w[e] << 16); a[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
+      } else {
+        a[0] = __uint_as_float(v.x); a[1] = __uint_as_float(v.y); a[2] = __uint_as_float(v.z); a[3] = __uint_as_float(v.w);
+      }
+      for (int64_t q = p + 1; q < n && keys[q] == key; ++q) {
+        const uint4 u = src[(int64_t)order[q] * chunks + c];
+        if (BF16) {
+          const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a[2 * e] += __uint_as_float(w[e] << 16); a[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+        } else {
+          a[0] += __uint_as_float(u.x); a[1] += __uint_as_float(u.y); a[2] += __uint_as_float(u.z); a[3] += __uint_as_float(u.w);
+        }
+      }
+      if (BF16) { v.x = pack_bf16x2(a[0], a[1]); v.y = pack_bf16x2(a[2], a[3]); v.z = pack_bf16x2(a[4], a[5]); v.w = pack_bf16x2(a[6], a[7]); }
+      else { v.x = __float_as_uint(a[0]); v.y = __float_as_uint(a[1]); v.z = __float_as_uint(a[2]); v.w = __float_as_uint(a[3]); }
+    }
+  }
+  dst[row * chunks + c] = v;
+}
+
+// rows of x that are not the winner of their voxel := 0 (in place)
+__global__ void k_dup_zero_rows(const int64_t* __restrict__ keys, const int32_t* __restrict__ order, uint4* __restrict__ x, int64_t n,
+                                int chunks) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * chunks) return;
+  const int64_t p = gid / chunks; const int c = (int)(gid - p * chunks);
+  if (p > 0 && keys[p - 1] == keys[p]) x[(int64_t)order[p] * chunks + c] = make_uint4(0, 0, 0, 0);
+}
+
+extern "C" int ss_dup_fold_rows(const void* src, const int64_t* sorted_keys, const int32_t* order, void* dst, int64_t n, int channels,
+                                int dtype, hipStream_t stream) {
+  const int64_t row_bytes = (int64_t)channels * (dtype == SS_BF16 ? 2 : 4);
+  if (n < 0 || n >= (1LL << 31) || channels <= 0 || (dtype != SS_F32 && dtype != SS_BF16) || (row_bytes & 15) ||
+      (((uintptr_t)src | (uintptr_t)dst) & 15) || src == dst)
+    return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  const int chunks = (int)(row_bytes >> 4);
+  if (dtype == SS_BF16)
+    SS_LAUNCH(k_dup_fold_rows<true>, dim3(ss_div_up(n * chunks, 256)), dim3(256), 0, stream, (const uint4*)src, sorted_keys, order,
+              (uint4*)dst, n, chunks);
+  else
+    SS_LAUNCH(k_dup_fold_rows<false>, dim3(ss_div_up(n * chunks, 256)), dim3(256), 0, stream, (const uint4*)src, sorted_keys, order,
+              (uint4*)dst, n, chunks);
+  return SS_OK;
+}
+
+extern "C" int ss_dup_zero_rows(const int64_t* sorted_keys, const int32_t* order, void* x, int64_t n, int64_t row_bytes,
+                                hipStream_t stream) {
+  if (n < 0 || n >= (1LL << 31) || row_bytes <= 0 || (row_bytes & 15) || ((uintptr_t)x & 15)) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  const int chunks = (int)(row_bytes >> 4);
+  SS_LAUNCH(k_dup_zero_rows, dim3(ss_div_up(n * chunks, 256)), dim3(256), 0, stream, sorted_keys, order, (uint4*)x, n, chunks);
+  return SS_OK;
+}

@@ -42,7 +42,8 @@ __device__ __forceinline__ float4 sf_row_or_zero(const float* __restrict__ base,
 template <int CI>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_subm_f32_fwd(const float* __restrict__ in, const float* __restrict__ wq, const float* __restrict__ bias,
-               const int32_t* __restrict__ nbr_walk, const int32_t* __restrict__ rowperm, float* __restrict__ out, int n, int taps) {
+               const int32_t* __restrict__ nbr_walk, const int32_t* __restrict__ rowperm, float* __restrict__ out, int n, int taps,
+               int winner_tap) {
   constexpr int NCH = CI / 4;                  // 16-byte chunks per input row
   constexpr int NQ = CI / 8;                   // k groups of 8 channels
   constexpr int NA = (32 * NCH) / 64;          // staging loads per lane and tap
@@ -54,6 +55,9 @@ k_subm_f32_fwd(const float* __restrict__ in, const float* __restrict__ wq, const
   const int m0 = (blockIdx.x * 4 + wave) * 32;
   if (m0 >= n) return;                                                              // wave-uniform
   const int site = (m0 + i < n) ? (rowperm ? rowperm[m0 + i] : m0 + i) : -1;
+  // duplicate voxels, adjoint pass (winner_tap = the centre tap, else -1): only the WINNER row of a voxel is ever read by the forward,
+  // so only winners receive a gradient; the centre tap of the rulebook names each site's winner
+  const int keep = (winner_tap < 0 || site < 0) ? 1 : (nbr_walk[(int64_t)winner_tap * n + m0 + i] == site ? 1 : 0);
   f32x16_t acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -122,7 +126,8 @@ k_subm_f32_fwd(const float* __restrict__ in, const float* __restrict__ wq, const
   for (int r = 0; r < 16; ++r) {
     const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
     const int s = __shfl(site, row, 64);
-    if (s >= 0) out[(int64_t)s * 32 + i] = acc[r] + bj;
+    const int kp = __shfl(keep, row, 64);
+    if (s >= 0) out[(int64_t)s * 32 + i] = kp ? acc[r] + bj : 0.f;
   }
 }
 
@@ -223,14 +228,28 @@ k_subm_f32_wgrad(const float* __restrict__ in, const float* __restrict__ g, cons
 
 extern "C" int ss_subm_f32_ok(int cin_padded, int cout) { return cout == 32 && (cin_padded == 16 || cin_padded == 32); }
 
-extern "C" int ss_subm_f32_fwd(const float* in, const float* wq, const float* bias, const int32_t* nbr_walk, const int32_t* rowperm,
-                               float* out, int64_t n, int cin_padded, int cout, int taps, hipStream_t stream) {
+static int subm_f32_launch(const float* in, const float* wq, const float* bias, const int32_t* nbr_walk, const int32_t* rowperm,
+                           float* out, int64_t n, int cin_padded, int cout, int taps, int winner_tap, hipStream_t stream) {
   if (n < 0 || n >= (1LL << 31) || taps <= 0 || !ss_subm_f32_ok(cin_padded, cout)) return SS_ERR_ARG;
   if (n == 0) return SS_OK;
   dim3 g(ss_div_up(n, 128)), b(256);
-  if (cin_padded == 16) SS_LAUNCH((k_subm_f32_fwd<16>), g, b, 0, stream, in, wq, bias, nbr_walk, rowperm, out, (int)n, taps);
-  else SS_LAUNCH((k_subm_f32_fwd<32>), g, b, 0, stream, in, wq, bias, nbr_walk, rowperm, out, (int)n, taps);
+  if (cin_padded == 16) SS_LAUNCH((k_subm_f32_fwd<16>), g, b, 0, stream, in, wq, bias, nbr_walk, rowperm, out, (int)n, taps, winner_tap);
+  else SS_LAUNCH((k_subm_f32_fwd<32>), g, b, 0, stream, in, wq, bias, nbr_walk, rowperm, out, (int)n, taps, winner_tap);
   return SS_OK;
+}
+
+extern "C" int ss_subm_f32_fwd(const float* in, const float* wq, const float* bias, const int32_t* nbr_walk, const int32_t* rowperm,
+                               float* out, int64_t n, int cin_padded, int cout, int taps, hipStream_t stream) {
+  return subm_f32_launch(in, wq, bias, nbr_walk, rowperm, out, n, cin_padded, cout, taps, -1, stream);
+}
+
+// dgrad on a level with duplicate voxels: dout_folded = ss_dup_fold_rows(dout) (gradients of a voxel's sites summed onto its winner),
+// wq = the tap-mirrored transposed weights; rows that are not the winner of their voxel come out as zeros (taps must be odd: the
+// centre tap of the rulebook is each site's winner)
+extern "C" int ss_subm_f32_dgrad_dup(const float* dout_folded, const float* wq, const int32_t* nbr_walk, const int32_t* rowperm,
+                                     float* din, int64_t n, int cin_padded, int cout, int taps, hipStream_t stream) {
+  if (!(taps & 1)) return SS_ERR_ARG;
+  return subm_f32_launch(dout_folded, wq, nullptr, nbr_walk, rowperm, din, n, cin_padded, cout, taps, taps / 2, stream);
 }
 
 // dweight (32, taps, cin) fp32 ZEROED by the caller; blk_count / blk_list from ss_subm_block_lists (same rowperm)

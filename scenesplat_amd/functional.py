@@ -156,10 +156,11 @@ class _SubMConv3dFused(torch.autograd.Function):
     (same kernel, tap-mirrored transposed weights) and wgrad; duplicate voxels handled exactly."""
 
     @staticmethod
-    def forward(ctx, feat, weight, bias, nbr, rowperm, blocks_fn, has_dup, walk_fn=None):
+    def forward(ctx, feat, weight, bias, nbr, rowperm, blocks_fn, has_dup, walk_fn=None, dup_fn=None):
         taps, n = nbr.shape
         cout, cin = weight.shape[0], weight.shape[-1]
         pad = (-cin) % 8
+        ctx.dup_fn = dup_fn
         x = feat.to(torch.bfloat16)
         w = bf16_of(weight).reshape(cout, taps, cin)
         if pad:
@@ -168,7 +169,7 @@ class _SubMConv3dFused(torch.autograd.Function):
         ctx.meta = (feat.dtype, weight.dtype, weight.shape, cin, bias is not None)
         ctx.blocks_fn, ctx.has_dup = blocks_fn, has_dup
         ctx.wt = mirrored_of(weight) if not pad else None      # dgrad weight kept beside the shadow (functional.register_mirrored)
-        ctx.im2col = (n <= CONV_IM2COL_MAX_SITES) and not has_dup
+        ctx.im2col = n <= CONV_IM2COL_MAX_SITES
         # bf16 out under autocast (the next op is a bf16 GEMM); outside autocast (the evaluator's call form) the output
         # keeps the input's dtype so that the fp32 Linear that follows sees what the reference's fp32 conv would hand it
         out_dtype = torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
@@ -195,36 +196,39 @@ class _SubMConv3dFused(torch.autograd.Function):
         in_dtype, w_dtype, w_shape, cin, has_bias = ctx.meta
         g = dout.to(torch.bfloat16).contiguous()
         dx = dw = db = None
+        # duplicate voxels (Mix3D batches): every site at a voxel reads the voxel's WINNER row, so the adjoint first folds the
+        # gradients of all duplicates onto their winner (ss_dup_fold_rows), runs the symmetric gather on that, and leaves the
+        # non-winner rows (which nobody reads) with zero gradient
+        runs = gd = None
+        if ctx.has_dup and ctx.needs_input_grad[0]:
+            runs = ctx.dup_fn() if ctx.dup_fn is not None else nv.dup_runs_from_rulebook(nbr)
+            gd = nv.dup_fold_rows(g, runs)
         if ctx.im2col:
             cols = x                                               # saved im2col(x): (n, taps * cin_padded)
             taps = nbr.shape[0]
             if ctx.needs_input_grad[0]:
                 wt = ctx.wt if ctx.wt is not None else nv.subm_weight_mirror(w)   # [ci][t'][co] = w[co][T-1-t'][ci]
-                dx = torch.nn.functional.linear(nv.subm_im2col(g, nbr), wt.view(wt.shape[0], -1))[:, :cin].to(in_dtype)
+                dx = torch.nn.functional.linear(nv.subm_im2col(g if gd is None else gd, nbr), wt.view(wt.shape[0], -1))
+                if runs is not None:
+                    nv.dup_zero_rows_(dx, runs)
+                dx = dx[:, :cin].to(in_dtype)
             if ctx.needs_input_grad[1]:
                 dw = _mm_f32(g.t(), cols).view(w.shape)[:, :, :cin].reshape(w_shape).to(w_dtype)
             if has_bias and ctx.needs_input_grad[2]:
                 db = g.sum(0, dtype=torch.float32).to(w_dtype)
-            return dx, dw, db, None, None, None, None, None
+            return dx, dw, db, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             wt = ctx.wt if ctx.wt is not None else nv.subm_weight_mirror(w)       # [ci][t'][co] = w[co][T-1-t'][ci]
-            if not ctx.has_dup:
-                dx = nv.subm_conv_fwd(g, wt, None, nbr, rowperm, nbr_walk=walk)[:, :cin].to(in_dtype)
-            else:
-                # duplicate voxels (Mix3D batches): every site at a voxel reads the voxel's WINNER row, so the
-                # adjoint first folds the gradients of all duplicates onto their winner, runs the symmetric
-                # gather on that, and leaves non-winner rows (which nobody reads) with zero gradient
-                winner = nbr[nbr.shape[0] // 2].long()
-                is_w = winner == torch.arange(winner.numel(), device=winner.device)
-                gsum = torch.zeros(g.shape, dtype=torch.float32, device=g.device).index_add_(0, winner, g.float())
-                dx = nv.subm_conv_fwd(gsum.to(torch.bfloat16), wt, None, nbr, rowperm)[:, :cin]
-                dx = (dx * is_w.unsqueeze(1)).to(in_dtype)
+            dx = nv.subm_conv_fwd(g if gd is None else gd, wt, None, nbr, rowperm, nbr_walk=walk)
+            if runs is not None:
+                nv.dup_zero_rows_(dx, runs)
+            dx = dx[:, :cin].to(in_dtype)
         if ctx.needs_input_grad[1]:
             blocks = ctx.blocks_fn() if ctx.blocks_fn is not None else nv.subm_block_lists(nbr, rowperm)
             dw = nv.subm_conv_wgrad(x, g, nbr, rowperm, blocks, nbr_walk=walk)[:, :, :cin].reshape(w_shape).to(w_dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = g.sum(0, dtype=torch.float32).to(w_dtype)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 def _split_bf16(t):
@@ -243,10 +247,11 @@ class _SubMConv3dSplit(torch.autograd.Function):
     (xh + xl) (x) gh + xh (x) gl.  3x the conv FLOPs of the bf16 mode."""
 
     @staticmethod
-    def forward(ctx, feat, weight, bias, nbr, rowperm, blocks_fn):
+    def forward(ctx, feat, weight, bias, nbr, rowperm, blocks_fn, has_dup=False, dup_fn=None):
         taps, n = nbr.shape
         cout, cin = weight.shape[0], weight.shape[-1]
         pad = (-cin) % 8
+        ctx.has_dup, ctx.dup_fn = has_dup, dup_fn
         x = feat.float()
         w = weight.float().reshape(cout, taps, cin)
         if pad:
@@ -269,8 +274,16 @@ class _SubMConv3dSplit(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wt3 = torch.cat([nv.subm_weight_mirror(wh), nv.subm_weight_mirror(wh), nv.subm_weight_mirror(wl)], 2).contiguous()
-            g3 = torch.cat([gh, gl, gh], 1).contiguous()
-            dx = nv.subm_conv_fwd(g3, wt3, None, nbr, rowperm, torch.float32)[:, :cin].to(in_dtype)
+            runs = None
+            fh, fl = gh, gl
+            if ctx.has_dup:      # duplicate voxels: fold the gradients of a voxel's sites onto its winner (fp32), then split
+                runs = ctx.dup_fn() if ctx.dup_fn is not None else nv.dup_runs_from_rulebook(nbr)
+                fh, fl = _split_bf16(nv.dup_fold_rows(dout.float().contiguous(), runs))
+            g3 = torch.cat([fh, fl, fh], 1).contiguous()
+            dx = nv.subm_conv_fwd(g3, wt3, None, nbr, rowperm, torch.float32)
+            if runs is not None:
+                nv.dup_zero_rows_(dx, runs)
+            dx = dx[:, :cin].to(in_dtype)
         if ctx.needs_input_grad[1]:
             blocks = ctx.blocks_fn() if ctx.blocks_fn is not None else nv.subm_block_lists(nbr, rowperm)
             cp = xh.shape[1]
@@ -279,20 +292,24 @@ class _SubMConv3dSplit(torch.autograd.Function):
             dw = (d2[:, :, :cp] + d2[:, :, cp:] + d1)[:, :, :cin].reshape(w_shape).to(w_dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = dout.sum(0, dtype=torch.float32).to(w_dtype)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class _SubMConv3dF32(torch.autograd.Function):
     """The 32-channel first stage in EXACT fp32 on the matrix cores (csrc/subm_f32.hip, v_mfma_f32_32x32x2_f32): what the reference
     computes for this op under AMP (spconv in fp32, pointcept/models/modules.py:64-75) without the 3x products and the hi/lo operand
-    copies of _SubMConv3dSplit.  Eligible: 32 output channels, at most 32 input channels, no duplicate voxels; the input gradient
-    needs 32 input channels (the stem's input is data and takes none)."""
+    copies of _SubMConv3dSplit.  Eligible: 32 output channels, at most 32 input channels; the input gradient needs 32 input channels
+    (the stem's input is data and takes none).  Duplicate voxels (Mix3D batches, datasets/utils.py:43-47 -- 80 % of the reference's
+    training steps): the forward and the weight gradient read winner rows through the rulebook as they are; the input gradient
+    folds the output gradients of a voxel's sites onto its winner first (ss_dup_fold_rows) and the kernel writes zeros to the
+    other rows (ss_subm_f32_dgrad_dup)."""
 
     @staticmethod
-    def forward(ctx, feat, weight, bias, nbr, rowperm, blocks_fn, walk_fn):
+    def forward(ctx, feat, weight, bias, nbr, rowperm, blocks_fn, walk_fn, has_dup=False, dup_fn=None):
         taps, n = nbr.shape
         cout, cin = weight.shape[0], weight.shape[-1]
         cp = 16 if cin <= 16 else 32
+        ctx.has_dup, ctx.dup_fn, ctx.plain_nbr = has_dup, dup_fn, nbr
         ctx.orig_nbr = nbr if blocks_fn is None else None
         nbr = walk_fn() if walk_fn is not None else nv.subm_walk_rulebook(nbr, rowperm)     # walk order from here on
         x = feat.float()
@@ -313,13 +330,18 @@ class _SubMConv3dF32(torch.autograd.Function):
         g = dout.float().contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = nv.subm_f32_fwd(g, nv.subm_f32_weight_layout(w, mirror=True), None, nbr, rowperm).to(in_dtype)
+            if ctx.has_dup:
+                runs = ctx.dup_fn() if ctx.dup_fn is not None else nv.dup_runs_from_rulebook(ctx.plain_nbr)
+                dx = nv.subm_f32_fwd(nv.dup_fold_rows(g, runs), nv.subm_f32_weight_layout(w, mirror=True), None, nbr, rowperm,
+                                     winners_only=True).to(in_dtype)
+            else:
+                dx = nv.subm_f32_fwd(g, nv.subm_f32_weight_layout(w, mirror=True), None, nbr, rowperm).to(in_dtype)
         if ctx.needs_input_grad[1]:
             blocks = ctx.blocks_fn() if ctx.blocks_fn is not None else nv.subm_block_lists(ctx.orig_nbr, rowperm)
             dw = nv.subm_f32_wgrad(x, g, nbr, rowperm, blocks, cin).reshape(w_shape).to(w_dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = g.sum(0, dtype=torch.float32).to(w_dtype)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 CONV_WALK_RULEBOOK = os.environ.get("SS_CONV_WALK", "1") != "0"    # 0: the pipeline conv kernels read the plain rulebook (A/B: scripts/ab_step.py conv_walk)
@@ -335,20 +357,23 @@ def _mm_f32(a, b):
         return torch.mm(a, b).float()
 
 
-def subm_conv3d(feat, weight, bias, nbr, has_dup=False, compute_dtype=torch.float32, rowperm=None, blocks_fn=None, walk_fn=None):
+def subm_conv3d(feat, weight, bias, nbr, has_dup=False, compute_dtype=torch.float32, rowperm=None, blocks_fn=None, walk_fn=None,
+                dup_fn=None):
     """weight (Cout, k, k, k, Cin) as in the reference checkpoints; nbr (k^3, n) tap-major.
     compute_dtype: torch.bfloat16 -> fused MFMA kernels on bf16 operands; "bf16x3" -> the reference's fp32 precision for this op on the
     matrix cores: exact fp32 MFMA for the 32-channel stage (walk_fn: the level's cached walk-order rulebook), else the bf16
-    kernels on hi/lo-split operands; torch.float32 -> per-tap gather + fp32 GEMM."""
+    kernels on hi/lo-split operands; torch.float32 -> per-tap gather + fp32 GEMM.
+    has_dup: the level holds duplicate voxels (Mix3D batches); dup_fn() -> (sorted keys, order) of the level (plan.Level.dup_runs),
+    derived from the rulebook when absent.  Every MFMA path handles duplicates itself (no per-tap detour)."""
     if compute_dtype == torch.bfloat16 and weight.shape[0] % 8 == 0:
-        return _SubMConv3dFused.apply(feat, weight, bias, nbr, rowperm, blocks_fn, has_dup, walk_fn)
+        return _SubMConv3dFused.apply(feat, weight, bias, nbr, rowperm, blocks_fn, has_dup, walk_fn, dup_fn)
     if compute_dtype == "bf16x3":
-        if (CONV_F32_MFMA and weight.shape[0] == 32 and weight.shape[-1] <= 32 and not has_dup and feat.is_cuda
+        if (CONV_F32_MFMA and weight.shape[0] == 32 and weight.shape[-1] <= 32 and feat.is_cuda
                 and (weight.shape[-1] == 32 or not feat.requires_grad)):
-            return _SubMConv3dF32.apply(feat, weight, bias, nbr, rowperm, blocks_fn, walk_fn)
-        if weight.shape[0] % 8 == 0 and not has_dup and feat.is_cuda:
-            return _SubMConv3dSplit.apply(feat, weight, bias, nbr, rowperm, blocks_fn)
-        compute_dtype = torch.float32            # duplicate voxels (Mix3D) / odd widths: the per-tap fp32 path
+            return _SubMConv3dF32.apply(feat, weight, bias, nbr, rowperm, blocks_fn, walk_fn, has_dup, dup_fn)
+        if weight.shape[0] % 8 == 0 and feat.is_cuda:
+            return _SubMConv3dSplit.apply(feat, weight, bias, nbr, rowperm, blocks_fn, has_dup, dup_fn)
+        compute_dtype = torch.float32            # odd widths: the per-tap fp32 path
     return _SubMConv3d.apply(feat, weight, bias, nbr, has_dup, compute_dtype)
 
 
@@ -365,14 +390,22 @@ class _Gelu(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        return nv.gelu(x, dy.contiguous().to(x.dtype))
+        dy = dy.contiguous().to(x.dtype)
+        if not _aligned16(dy):
+            dy = dy.clone()
+        return nv.gelu(x, dy)
 
 
 GELU_HIP = os.environ.get("SS_GELU_HIP", "1") != "0"       # 0: torch's elementwise GELU kernels (A/B: scripts/ab_step.py gelu)
 
 
+def _aligned16(t):
+    return t.data_ptr() % 16 == 0 and t.storage_offset() * t.element_size() % 16 == 0
+
+
 def gelu(x):
-    if GELU_HIP and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+    # (ss_gelu moves 16-byte lanes: a contiguous slice at an odd storage offset takes torch's kernel instead of an argument error)
+    if GELU_HIP and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and _aligned16(x):
         return _Gelu.apply(x)
     return torch.nn.functional.gelu(x)
 
@@ -502,7 +535,8 @@ def refresh_shadows(src, dst):
         # one launch for all of them (torch._foreach_copy_ with a dtype change is one copy kernel PER TENSOR: 206 launches and
         # 1.2 ms per step on the lang-pretrain model); anything that is not a contiguous fp32 -> bf16 pair takes the torch path
         fast = [(s_, d_) for s_, d_ in zip(todo_s, todo_d) if s_.is_cuda and s_.dtype == torch.float32 and d_.dtype == torch.bfloat16
-                and s_.is_contiguous() and d_.is_contiguous() and s_.numel() == d_.numel()]
+                and s_.is_contiguous() and d_.is_contiguous() and s_.numel() == d_.numel()
+                and s_.data_ptr() % 16 == 0 and d_.data_ptr() % 16 == 0]      # (the group kernel moves 16-byte lanes from the tensor base)
         if SHADOW_GROUP_CAST and fast:
             nv.cast_bf16_group([a for a, _ in fast], [b for _, b in fast])
             if len(fast) != len(todo_s):
@@ -710,7 +744,10 @@ class _LinearGelu(torch.autograd.Function):
     def backward(ctx, dy):
         x, w16, u = ctx.saved_tensors
         w_dtype, has_bias = ctx.meta
-        du = nv.gelu(u, dy.contiguous())
+        dy = dy.contiguous()
+        if not _aligned16(dy):
+            dy = dy.clone()                     # a fresh allocation is 16-byte aligned (ss_gelu's lanes)
+        du = nv.gelu(u, dy)
         dx, dw, db = _linear_backward(x, w16, ctx.dgrad_nt, w_dtype, has_bias, ctx.stage, du, ctx.needs_input_grad[0],
                                       ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dx, dw, db, None, None, None, None

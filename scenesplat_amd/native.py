@@ -392,9 +392,10 @@ def subm_walk_rulebook(nbr, rowperm):
     return nbr if rowperm is None else nbr.index_select(1, rowperm).contiguous()
 
 
-def subm_f32_fwd(x, wq, bias, nbr, rowperm):
+def subm_f32_fwd(x, wq, bias, nbr, rowperm, winners_only=False):
     """x (n, cp) f32 (cp 16 | 32), wq from subm_f32_weight_layout, nbr = subm_walk_rulebook(...) -> (n, 32) f32, exact fp32
-    products (v_mfma_f32_32x32x2_f32)."""
+    products (v_mfma_f32_32x32x2_f32).  winners_only: the dgrad form for a level with duplicate voxels -- x = dup_fold_rows(dout),
+    rows that are not the winner of their voxel come out as zeros."""
     n, cp = x.shape
     taps = nbr.shape[0]
     _req(x, torch.float32, "x"); _req(wq, torch.float32, "wq", (taps, cp // 8, 2, 32, 4)); _req(nbr, torch.int32, "nbr", (taps, n))
@@ -403,8 +404,41 @@ def subm_f32_fwd(x, wq, bias, nbr, rowperm):
     if rowperm is not None:
         _req(rowperm, torch.int32, "rowperm", (n,))
     out = torch.empty((n, 32), dtype=torch.float32, device=x.device)
+    if winners_only:
+        if bias is not None:
+            raise RuntimeError("subm_f32_fwd: the dgrad form takes no bias")
+        check(lib().ss_subm_f32_dgrad_dup(_p(x), _p(wq), _p(nbr), _p(rowperm), _p(out), n, cp, 32, taps, _stream()), "ss_subm_f32_dgrad_dup")
+        return out
     check(lib().ss_subm_f32_fwd(_p(x), _p(wq), _p(bias), _p(nbr), _p(rowperm), _p(out), n, cp, 32, taps, _stream()), "ss_subm_f32_fwd")
     return out
+
+
+def dup_runs_from_rulebook(nbr):
+    """(sorted keys (n) int64, order (n) int32) naming the duplicate-voxel runs of a level, derived from a rulebook alone: the centre
+    tap of nbr (taps, n) is every site's winner row, a stable sort by it lists each voxel's rows ascending behind their winner.
+    (A ScenePlan level hands out its curve codes instead: Level.dup_runs.)"""
+    keys, order = torch.sort(nbr[nbr.shape[0] // 2].long(), stable=True)
+    return keys.contiguous(), order.to(torch.int32).contiguous()
+
+
+def dup_fold_rows(src, runs):
+    """Adjoint of "every site of a voxel reads the voxel's winner row": out[winner] = sum of src over the voxel's rows (fp32
+    accumulate, deterministic), out[other rows] = 0.  src (n, C) f32 | bf16 with 16-byte rows; runs = (sorted keys, order)."""
+    keys, order = runs
+    n, C = src.shape
+    _req(src, None, "src"); _req(keys, torch.int64, "sorted_keys", (n,)); _req(order, torch.int32, "order", (n,))
+    out = torch.empty_like(src)
+    check(lib().ss_dup_fold_rows(_p(src), _p(keys), _p(order), _p(out), n, C, dtype_code(src), _stream()), "ss_dup_fold_rows")
+    return out
+
+
+def dup_zero_rows_(x, runs):
+    """In place: rows of x (n, C) that are not the winner of their voxel := 0."""
+    keys, order = runs
+    n = x.shape[0]
+    _req(x, None, "x"); _req(keys, torch.int64, "sorted_keys", (n,)); _req(order, torch.int32, "order", (n,))
+    check(lib().ss_dup_zero_rows(_p(keys), _p(order), _p(x), n, x.shape[1] * x.element_size(), _stream()), "ss_dup_zero_rows")
+    return x
 
 
 def subm_f32_wgrad(x, dout, nbr, rowperm, blocks, cin):

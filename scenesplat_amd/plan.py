@@ -146,6 +146,12 @@ class Level:
             self._nbr[key] = w
         return w
 
+    def dup_runs(self):
+        """(sorted codes (n) int64, order (n) int32) of the first curve: runs of equal codes = the rows of one voxel, ascending, the
+        winner (lowest row, what the rulebook resolves a voxel to) first -- what ss_dup_fold_rows / ss_dup_zero_rows walk on a
+        level with duplicate voxels (Mix3D batches).  Rows of the plan's own buffers: nothing to build, replay-safe."""
+        return self.codes_sorted[0], self.order[0]
+
     def neighbors(self, ksize):
         """(k^3, n) int32 tap-major rulebook, shared by every conv of this level (indice_key)."""
         nb = self._nbr.get(ksize)
@@ -257,13 +263,20 @@ class ScenePlan:
 
     def materialize(self, window_specs=(), kernel_sizes=()):
         """Build the lazily cached pieces now (on the current stream): window_specs = [(level, curve index,
-        patch)], kernel_sizes = [(level, k) | (level, k, True: also the walk-order rulebook)]."""
+        patch)], kernel_sizes = [(level, k) | (level, k, walk)], walk = True (also the walk-order rulebook) or the list of the
+        channel widths of the level's convs: the walk-order rulebook is built when one of them will read it (the forward's own
+        predicate, pointcept_api.ptv3.conv_wants_walk -- so a captured plan and every later plan hold the same pieces)."""
         for li, j, patch in window_specs:
             self.levels[li].window(j, patch)
         for li, k, *walk in kernel_sizes:
-            self.levels[li].neighbors(k); self.levels[li].conv_blocks(k)
-            if walk and walk[0]:
-                self.levels[li].neighbors_walk(k)
+            lv = self.levels[li]
+            lv.neighbors(k); lv.conv_blocks(k)
+            want = walk[0] if walk else False
+            if isinstance(want, (list, tuple)):
+                from .pointcept_api.ptv3 import conv_wants_walk
+                want = any(conv_wants_walk(lv.n, c, k) for c in want)
+            if want:
+                lv.neighbors_walk(k)
 
     def record_stream(self, stream):
         """The plan was allocated on another stream: keep the caching allocator from reusing its memory
@@ -340,6 +353,14 @@ def build_plan(grid_coord, offset, order_names, strides, perms=None, depth=None)
     return ScenePlan(levels, list(order_names))
 
 
+# torch's synchronisation detector (torch.cuda.set_sync_debug_mode) is PROCESS-wide.  steady_state.py arms it for one eager step per
+# plan signature; a plan build on another thread reads sizes on the host and would trip it.  Both sides take this gate: a build holds
+# it while it runs (so the detector is never armed in the middle of one), steady_state holds it while the detector is armed (so no
+# build starts inside the window) -- the plan thread simply waits at the gate for that one step.
+HOST_SYNC_GATE = __import__("threading").Lock()
+PLAN_BUILD_MAX_RETRIES = 200     # x 5 ms: a build that still trips a detector somebody else left armed becomes an error, not a hang
+
+
 class PlanAhead:
     """Integer plans built by a HOST THREAD, `depth` steps ahead of the float pipeline.
 
@@ -370,14 +391,18 @@ class PlanAhead:
         try:
             if self._device is not None:
                 torch.cuda.set_device(self._device)
+            retries = 0
             while not self._stop:
                 try:
-                    plan = self._build()
+                    with HOST_SYNC_GATE:            # never while steady_state has torch's process-wide sync detector armed
+                        plan = self._build()
+                    retries = 0
                 except RuntimeError as e:
-                    # torch's synchronisation detector is PROCESS-wide: while another thread has it armed (steady_state.py runs
-                    # one eager step under set_sync_debug_mode("error") before it captures) the build's host round trips raise
-                    # here.  Not a failure of the build: wait for the window to pass and build again.
-                    if "synchronizing" in str(e) and not self._stop:
+                    # The gate keeps this library's own detector window away from the build.  A detector armed by somebody else
+                    # (user code calling torch.cuda.set_sync_debug_mode("error")) still makes the build's host round trips raise:
+                    # retried for a bounded time (it may be a short window), then handed to the consumer as the error it is.
+                    if "synchronizing" in str(e) and not self._stop and retries < PLAN_BUILD_MAX_RETRIES:
+                        retries += 1
                         time.sleep(0.005)
                         continue
                     raise

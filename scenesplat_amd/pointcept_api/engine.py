@@ -426,3 +426,60 @@ class Trainer(TrainerBase):
         self.optimizer.step()
         self.scheduler.step()
         self.comm_info["model_output_dict"] = out
+
+
+# ---- multi-dataset training (engines/train.py:346-374, datasets/dataloader.py:23-102) ---------------------------------------
+class MultiDatasetLoader:
+    """The batch schedule of the reference's MultiDatasetDataloader over already-built per-dataset loaders (data loading itself is
+    outside the hot path and injected, as for Trainer): every batch comes from ONE dataset; a round takes ratios[i] batches from
+    loader i in turn; the FIRST loader defines the epoch (the iteration ends when it is exhausted), the others restart when they
+    run out.  len() = the number of batches of one such epoch."""
+
+    def __init__(self, dataloaders, ratios):
+        self.dataloaders, self.ratios = list(dataloaders), [int(r) for r in ratios]
+        if not self.dataloaders or len(self.dataloaders) != len(self.ratios) or min(self.ratios) < 1:
+            raise ValueError("MultiDatasetLoader: one positive ratio per loader")
+        self.sampler = self            # Trainer.train calls train_loader.sampler.set_epoch under DDP (dataloader.py:115-121)
+
+    def set_epoch(self, epoch):
+        for dl in self.dataloaders:
+            s = getattr(dl, "sampler", None)
+            if hasattr(s, "set_epoch"):
+                s.set_epoch(epoch)
+
+    def __iter__(self):
+        its = [iter(dl) for dl in self.dataloaders]
+        while True:
+            for i, r in enumerate(self.ratios):
+                for _ in range(r):
+                    try:
+                        batch = next(its[i])
+                    except StopIteration:
+                        if i == 0:
+                            return
+                        its[i] = iter(self.dataloaders[i])
+                        batch = next(its[i])
+                    yield batch
+
+    def __len__(self):
+        full, rem = divmod(len(self.dataloaders[0]), self.ratios[0])
+        return full * sum(self.ratios) + rem
+
+
+@TRAINERS.register_module("MultiDatasetTrainer")
+class MultiDatasetTrainer(Trainer):
+    """The trainer type of the concat-dataset language configs (configs/concat_dataset/lang-pretrain-...-contrastive.py:111-112;
+    engines/train.py:346-374): batches follow MultiDatasetLoader's schedule, `iter_per_epoch` is the length of that schedule and the
+    scheduler's total_steps = iter_per_epoch x (max_epoch - start_epoch).  train_loader: a MultiDatasetLoader, or a list of
+    (loader, ratio) pairs (ratio = the dataset's `loop` in the reference's config)."""
+
+    def __init__(self, cfg, train_loader=None, logger=None):
+        if not isinstance(train_loader, MultiDatasetLoader):
+            pairs = list(train_loader or [])
+            train_loader = MultiDatasetLoader([p[0] for p in pairs], [p[1] for p in pairs])
+        cfg = dict(cfg)
+        sched = dict(cfg["scheduler"])
+        sched["total_steps"] = max(1, len(train_loader)) * (cfg.get("eval_epoch", 1) - 0)     # start_epoch is 0 before any resume
+        cfg["scheduler"] = sched
+        super().__init__(cfg, train_loader=train_loader, logger=logger)
+        self.comm_info["iter_per_epoch"] = len(train_loader)

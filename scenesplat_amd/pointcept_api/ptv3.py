@@ -45,6 +45,20 @@ def bench_runtime():
                 conv_split_max_channels=int(os.environ.get("SS_CONV_SPLIT_MAX", "32")))
 
 
+def conv_wants_walk(n_sites, channels, ksize):
+    """Does a conv of this width -- an int (cin = cout) or a (cin, cout) pair -- on a level of n_sites read the walk-order rulebook?
+    The forward's own decisions (functional.subm_conv3d): the exact-fp32 first-stage kernels always do, the bf16 path where the
+    shape runs on the pipeline kernel."""
+    cin, cout = channels if isinstance(channels, (tuple, list)) else (channels, channels)
+    cd = conv_dtype_for(cout)
+    if cd == "bf16x3":
+        return bool(SF.CONV_F32_MFMA and cout == 32 and cin <= 32)
+    if cd == torch.bfloat16 and cout % 8 == 0:
+        return bool(SF.CONV_WALK_RULEBOOK and n_sites > SF.CONV_IM2COL_MAX_SITES
+                    and nv.subm_conv_fwd_uses_pipe(n_sites, cin + (-cin) % 8, cout, ksize ** 3))
+    return False
+
+
 def conv_dtype_for(out_channels):
     """RUNTIME["conv_dtype"] for a conv of this width: bf16 convs up to conv_split_max_channels run as "bf16x3"."""
     cd = RUNTIME["conv_dtype"] or torch.float32
@@ -89,7 +103,8 @@ class SubMConv3d(nn.Module):
         cd = conv_dtype_for(self.weight.shape[0])
         return SF.subm_conv3d(feat, self.weight, self.bias, level.neighbors(self.kernel_size),
                               level.has_duplicates, cd, level.conv_rowperm(),
-                              lambda: level.conv_blocks(self.kernel_size), lambda: level.neighbors_walk(self.kernel_size))
+                              lambda: level.conv_blocks(self.kernel_size), lambda: level.neighbors_walk(self.kernel_size),
+                              level.dup_runs)
 
 
 def _lin(mod, x):
@@ -286,6 +301,26 @@ class _Stage(nn.Module):
     pass
 
 
+def backward_in_two(outputs, grad_outputs, cut, between=None):
+    """The backward pass of a forward that was given data_dict["backward_cut"] = cut, in two autograd calls: first down to the
+    inputs of the last decoder stage (every gradient of that stage's parameters is final then), `between()` (e.g. pack that stage
+    and start its all-reduce), then the rest from the gradients the cut's leaves received.  With an empty cut (evaluation, no
+    decoder) it is one ordinary backward."""
+    torch.autograd.backward(outputs, grad_tensors=grad_outputs)
+    if between is not None:
+        between()
+    backward_tail(cut)
+
+
+def backward_tail(cut):
+    """Second call of backward_in_two: from the tensors the cut detached, with the gradients its leaves received."""
+    pairs = [(o, l.grad) for o, l in cut if l.grad is not None]
+    if pairs:
+        torch.autograd.backward([o for o, _ in pairs], grad_tensors=[g for _, g in pairs])
+    for _, l in cut:
+        l.grad = None
+
+
 @MODELS.register_module("PT-v3m1")
 class PointTransformerV3(PointModule):
     def __init__(self, in_channels=6, order=("z", "z-trans"), stride=(2, 2, 2, 2), enc_depths=(2, 2, 2, 6, 2),
@@ -357,15 +392,14 @@ class PointTransformerV3(PointModule):
     def plan_specs(self):
         """Everything the float pipeline will ask the plan for: (window specs, conv kernel sizes)."""
         K = len(self.order)
-        # 32-channel convs at the reference's fp32 precision run on the fp32-MFMA kernels, which read the rulebook in walk order
-        walk = [SF.CONV_F32_MFMA and c == 32 and conv_dtype_for(c) == "bf16x3" for c in self.enc_channels]
-        # ... and so does the bf16 pipeline conv of the wide stages (>= 256 channels on that level, encoder or decoder side)
+        # which convs read the rulebook in WALK order is decided per level by the same predicates the forward uses
+        # (ScenePlan.materialize -> conv_wants_walk below): the widths of the convs of each level travel with the spec
         wide = list(self.enc_channels)
         if not self.cls_mode:
             for s, c in enumerate(self.dec_channels_):
                 wide[s] = max(wide[s], c)
-        walk = [w or (c >= 256 and conv_dtype_for(c) == torch.bfloat16) for w, c in zip(walk, wide)]
-        wins, ks = [], [(0, 5, walk[0])]
+        walk = [[c for c in {self.enc_channels[s], wide[s]}] for s in range(self.num_stages)]
+        wins, ks = [], [(0, 5, [(self.embedding.in_channels, self.enc_channels[0])])]
         for s in range(self.num_stages):
             enc = getattr(self.enc, f"enc{s}")
             ks.append((s, 3, walk[s]))
@@ -515,8 +549,16 @@ class PointTransformerV3(PointModule):
             SF.stage_end()
         lv = self.num_stages - 1
         if not self.cls_mode:
+            # backward cut (data_dict["backward_cut"] = [], training): the inputs of the LAST decoder stage -- the first one the
+            # backward pass finishes, 52 % of the parameter bytes in the lang-pretrain model -- become leaves, so that the caller
+            # can run the backward in two calls (backward_in_two below) and start the gradient exchange of that stage in between
+            cut = point.get("backward_cut", None) if torch.is_grad_enabled() else None
             for s in reversed(range(self.num_stages - 1)):
                 dec = getattr(self.dec, f"dec{s}")
+                if cut is not None and s == 0 and x.requires_grad:
+                    leaves = (x.detach().requires_grad_(True), skips[0].detach().requires_grad_(True))
+                    cut.extend([(x, leaves[0]), (skips[0], leaves[1])])
+                    x, skips[0] = leaves
                 SF.stage_begin(self._stage_linears(dec), levels[s].n)
                 x, conv_in = dec.up(x, skips[s], levels[s + 1])
                 xb = None

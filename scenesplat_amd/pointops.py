@@ -31,7 +31,9 @@ def offset2batch(offset):
 
 
 def batch2offset(batch):
-    return torch.cumsum(batch.bincount(), dim=0).int()
+    b = batch.long()
+    nb = int(b.max()) + 1 if b.numel() else 0
+    return torch.zeros(nb, dtype=torch.long, device=b.device).scatter_add_(0, b, torch.ones_like(b)).cumsum(0).int()
 
 
 # ---- queries -----------------------------------------------------------------------------------

@@ -29,10 +29,11 @@ import torch
 
 from . import functional as SF
 from . import native as nv
+from .plan import HOST_SYNC_GATE
 
 
 class _Captured:
-    __slots__ = ("graph", "plan", "inputs", "outputs", "grads", "keep")
+    __slots__ = ("graph", "graph2", "plan", "inputs", "outputs", "grads", "keep")
 
 
 class CaptureInvalidated(RuntimeError):
@@ -51,10 +52,15 @@ class SteadyStateStep:
         returns them detached;
     params: the parameters whose .grad the step writes (their .grad is cleared before a capture);
     warmup: eager runs of a signature before it is captured (allocator pools, hipBLASLt heuristics, lazy code objects);
-    max_graphs: signatures kept (least recently used is dropped; a captured step owns its activations' memory)."""
+    max_graphs: signatures kept (least recently used is dropped; a captured step owns its activations' memory);
+    tail, between (round 4, the split step of a data-parallel run): the step is fn(plan, inputs) -- forward + the first part of
+        the backward --, then between() ON THE HOST, OUTSIDE any graph (it starts the gradient all-reduce of the stages that are
+        final: a collective is never captured), then tail() -- the rest of the backward, working on what fn left in the
+        caller's closure.  Captured as TWO graphs sharing one memory pool; a replay is graph 1, between(), graph 2."""
 
-    def __init__(self, fn, params, warmup=2, max_graphs=2, enabled=True):
+    def __init__(self, fn, params, warmup=2, max_graphs=2, enabled=True, tail=None, between=None):
         self.fn, self.params = fn, list(params)
+        self.tail, self.between = tail, between
         self.warmup, self.max_graphs, self.enabled = int(warmup), int(max_graphs), bool(enabled)
         self._seen, self._graphs = {}, {}
         self._refused = {}             # signature -> repr of what refused its capture: THAT signature runs eagerly from then on
@@ -68,10 +74,21 @@ class SteadyStateStep:
     def _signature(plan, inputs, key=None):
         return (plan.signature(), key) + tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(inputs.items()))
 
-    def _eager(self, plan, inputs):
+    def _eager(self, plan, inputs, arm=None):
         # outputs are handed out DETACHED: a caller holding on to them must not keep this step's autograd graph alive
         self.eager_steps += 1
-        return {k: v.detach() for k, v in self.fn(plan, inputs).items()}
+        out = {k: v.detach() for k, v in self.fn(plan, inputs).items()}
+        if self.tail is not None:
+            if self.between is not None:
+                # the collective launch is host code outside the graphs: not part of what the sync check must clear (a gloo
+                # all-reduce of device tensors reads them on the host)
+                if arm is not None:
+                    arm(False)
+                self.between()
+                if arm is not None:
+                    arm(True)
+            self.tail()
+        return out
 
     def __call__(self, plan, inputs, key=None):
         """key: hashable summary of every HOST-side value the step's control flow depends on (a loss schedule gate, a mode
@@ -97,11 +114,19 @@ class SteadyStateStep:
                 self._checked.add(sig)
                 main, side = torch.cuda.current_stream(), torch.cuda.Stream()
                 side.wait_stream(main)
-                torch.cuda.set_sync_debug_mode("error")
+                # the detector is process-wide: plan builds on other threads (plan.PlanAhead) wait at the gate while it is armed
+                armed = [False]
+
+                def arm(on):
+                    if on and not armed[0]:
+                        HOST_SYNC_GATE.acquire(); torch.cuda.set_sync_debug_mode("error"); armed[0] = True
+                    elif not on and armed[0]:
+                        torch.cuda.set_sync_debug_mode("default"); HOST_SYNC_GATE.release(); armed[0] = False
+                arm(True)
                 try:
                     with warnings.catch_warnings(record=True) as seen, torch.cuda.stream(side):
                         warnings.simplefilter("always")
-                        out = self._eager(plan, inputs)
+                        out = self._eager(plan, inputs, arm)
                     stale = [w for w in seen if "AccumulateGrad node's stream" in str(w.message)]
                     if stale:
                         raise RuntimeError("an autograd graph of an earlier step is still referenced (keep only detached "
@@ -109,12 +134,12 @@ class SteadyStateStep:
                     main.wait_stream(side)
                     return out
                 except Exception as e:  # noqa: BLE001
-                    torch.cuda.set_sync_debug_mode("default")
+                    arm(False)
                     main.wait_stream(side)
                     self._refuse(e, sig)
                     return self._eager(plan, inputs)
                 finally:
-                    torch.cuda.set_sync_debug_mode("default")
+                    arm(False)
             try:
                 cap = self._capture(plan, inputs)
             except CaptureInvalidated as e:
@@ -130,10 +155,21 @@ class SteadyStateStep:
                 self._graphs.pop(next(iter(self._graphs)))
         else:
             self._graphs[sig] = self._graphs.pop(sig)          # most recently used last
-            cap.plan.load_from(plan)
+            try:
+                cap.plan.load_from(plan)
+            except ValueError as e:
+                # the new plan holds other lazily built pieces than the captured one (e.g. a walk-order rulebook the model's
+                # plan_specs did not announce): nothing has been launched yet -- this signature runs eagerly from now on
+                self._graphs.pop(sig, None)
+                self._refuse(e, sig, sync=False)
+                return self._eager(plan, inputs)
             names = sorted(inputs)
             torch._foreach_copy_([cap.inputs[k] for k in names], [inputs[k] for k in names])
         cap.graph.replay()
+        if cap.graph2 is not None:
+            if self.between is not None:
+                self.between()
+            cap.graph2.replay()
         for p, g in cap.grads:
             p.grad = g
         self.replays += 1
@@ -164,6 +200,7 @@ class SteadyStateStep:
             p.grad = None
         cap.keep = nv.DescriptorPool()
         cap.graph = torch.cuda.CUDAGraph()
+        cap.graph2 = torch.cuda.CUDAGraph() if self.tail is not None else None
         main = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         torch.cuda.synchronize()
@@ -194,6 +231,23 @@ class SteadyStateStep:
                     _ABANDONED.append(cap.graph)
                     raise CaptureInvalidated("hipGraph capture invalidated by a call inside the step (no Python error)")
                 cap.graph.capture_end()
+                if cap.graph2 is not None:
+                    # second graph of a split step: the rest of the backward, in the SAME memory pool (it reads what graph 1
+                    # saved for it and frees it as it goes).  between() is not called here: a capture executes nothing.
+                    cap.graph2.capture_begin(pool=cap.graph.pool(), capture_error_mode="thread_local")
+                    try:
+                        self.tail()
+                    except BaseException as e:
+                        status = nv.stream_capture_status(side)
+                        if status == 1:
+                            cap.graph2.capture_end()
+                            raise
+                        _ABANDONED.extend([cap.graph, cap.graph2])
+                        raise CaptureInvalidated(f"hipGraph capture (second graph) invalidated (status {status}) by: {e!r}") from e
+                    if nv.stream_capture_status(side) != 1:
+                        _ABANDONED.extend([cap.graph, cap.graph2])
+                        raise CaptureInvalidated("hipGraph capture (second graph) invalidated by a call inside the step")
+                    cap.graph2.capture_end()
         finally:
             nv.CAPTURE_POOL = None
         main.wait_stream(side)

@@ -168,7 +168,14 @@ class _Staged(nn.Module):
     def forward(self, d):
         h = torch.tanh(self.embedding(d["feat"]))
         h = torch.tanh(self.enc["enc0"](h)) + h
-        h = self.enc["enc1"]["block0"](torch.tanh(self.enc["enc1"]["down"](h))) + self.enc["enc0"](h)     # enc0 used twice
+        if d.get("skip_enc1"):                 # a data-dependent branch: enc1 receives no gradient this step (on this rank)
+            h = self.enc["enc0"](h)
+        else:
+            h = self.enc["enc1"]["block0"](torch.tanh(self.enc["enc1"]["down"](h))) + self.enc["enc0"](h)     # enc0 used twice
+        cut = d.get("backward_cut")
+        if cut is not None:                    # the backward cut of PointTransformerV3.forward, in miniature
+            leaf = h.detach().requires_grad_(True)
+            cut.append((h, leaf)); h = leaf
         return dict(loss=self.dec["dec0"](h).pow(2).mean())
 
 
@@ -178,20 +185,34 @@ def _stage_worker(rank, world, port, q, hooks=True):
     from scenesplat_amd.grad_exchange import StageGradExchange, default_stage_of
     torch.manual_seed(0)
     model = _Staged()
-    ex = StageGradExchange(model, hooks=hooks)
+    ex = StageGradExchange(model, hooks=(hooks is True))
     assert set(ex.stages) == {"embedding", "enc.enc0", "enc.enc1", "dec.dec0", "other"}
     assert default_stage_of("module.backbone.dec.dec0.block1.mlp.0.fc1.weight") == "dec.dec0"
     opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    from scenesplat_amd.pointcept_api.ptv3 import backward_tail
+    assert [st["label"] for st in ex._sequence] == ["other", "dec.dec0", "enc.enc1", "enc.enc0", "embedding"]     # fixed launch order
+    # the early stage sits at the front of the allocation: two contiguous slices
+    (ent,) = ex.whole.values()
+    assert ex.stages["dec.dec0"]["flat"].data_ptr() == ent[1].data_ptr() and 0 < ent[2] < ent[1].numel()
     for it, d in enumerate(_loader(3, seed=200 + rank)):
         if it == 1:
             opt.zero_grad(set_to_none=False)       # gradients stay the stage-buffer views: accumulated in place, no pack copy
         else:
             opt.zero_grad(set_to_none=True)
-        model(d)["loss"].backward()
-        if hooks:
-            ex.finish()
+        if it == 2 and rank == 1:
+            d = dict(d, skip_enc1=True)            # enc1 takes no part on THIS rank only: the collective sequence must not change
+        if hooks == "split":
+            cut = []
+            model(dict(d, backward_cut=cut))["loss"].backward()       # down to the cut: dec0's gradients are final
+            ex.pack("early"); ex.reduce_begin("early")
+            backward_tail(cut)
+            ex.pack("late"); ex.reduce_begin("late"); ex.reduce_end()
         else:
-            ex.pack(); ex.reduce()             # the packed form of graph-replayed steps: pack inside the step, all-reduce after it
+            model(d)["loss"].backward()
+            if hooks:
+                ex.finish()
+            else:
+                ex.pack(); ex.reduce()             # the packed form of graph-replayed steps: pack inside the step, all-reduce after it
         assert model.unused.weight.grad is not None and float(model.unused.weight.grad.abs().sum()) == 0.0
         for st in ex.stages.values():
             for p, v in zip(st["params"], st["views"]):
@@ -203,11 +224,13 @@ def _stage_worker(rank, world, port, q, hooks=True):
 
 
 @pytest.mark.timeout(180)
-@pytest.mark.parametrize("hooks", [True, False])
+@pytest.mark.parametrize("hooks", [True, False, "split"])
 def test_stage_grad_exchange_world_size_2_gloo_matches_hand_average(hooks):
-    """One all-reduce per model stage -- launched from post-accumulate hooks during the backward, or (hooks=False) packed at the end
-    of the step and reduced after it: both ranks end with the weights of a single process that averages the two shards'
-    gradients by hand (what DDP computes, engines/defaults.py:13-34)."""
+    """One all-reduce per model stage -- launched from post-accumulate hooks during the backward in a FIXED order, or (hooks=False)
+    packed at the end of the step and reduced after it, or ("split", round 4) the two-call backward with the early slice (dec0)
+    all-reduced while the rest of the backward runs: both ranks end with the weights of a single process that averages the two
+    shards' gradients by hand (what DDP computes, engines/defaults.py:13-34) -- including a step in which one stage receives no
+    gradient on ONE rank only."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -221,9 +244,9 @@ def test_stage_grad_exchange_world_size_2_gloo_matches_hand_average(hooks):
     torch.manual_seed(0)
     model = _Staged()
     opt = torch.optim.SGD(model.parameters(), lr=0.1)
-    for a, b in zip(_loader(3, seed=200), _loader(3, seed=201)):
+    for it, (a, b) in enumerate(zip(_loader(3, seed=200), _loader(3, seed=201))):
         opt.zero_grad(set_to_none=True)
-        ((model(a)["loss"] + model(b)["loss"]) / 2).backward()
+        ((model(a)["loss"] + model(dict(b, skip_enc1=(it == 2)))["loss"]) / 2).backward()
         opt.step()
     for k, v in model.state_dict().items():
         assert torch.allclose(torch.as_tensor(res[0][1][k]), v, atol=1e-6), k

@@ -130,3 +130,40 @@ def test_duplicate_voxels_detected_and_resolved_to_lowest_row(nv):
     assert lv.has_duplicates
     assert np.array_equal(lv.order_row(0).cpu().numpy(), np.argsort(oser.encode(gc, np.zeros(5, int), lv.depth, "z"), kind="stable"))
     assert np.array_equal(lv.neighbors(3).cpu().numpy().T, oops.neighbor_table(gc, np.zeros(5, int), 3))
+
+
+def test_point_publishes_reference_shaped_keys_from_the_plan(nv, golden_dir):
+    """Point.serialization / serialized_* / sparsify / padding() (reference structure.py:47-140, ptv3:114-170) against the
+    reference's own outputs: the room fixture of serialization.npz and every case of padding.npz."""
+    from scenesplat_amd.pointcept_api.structure import Point
+    fx = np.load(os.path.join(golden_dir, "serialization.npz"))
+    gc = dev(fx["room_gc"])
+    p = Point(grid_coord=gc, offset=dev(fx["room_offset"]), feat=torch.zeros(len(gc), 4, device="cuda"))
+    p.serialization(order=ORD)
+    assert p.serialized_depth == int(fx["room_depth"])
+    for key, ref in (("serialized_code", "room_code"), ("serialized_order", "room_order"), ("serialized_inverse", "room_inverse")):
+        assert p[key].dtype == torch.int64 and np.array_equal(p[key].cpu().numpy(), fx[ref]), key
+    sp = p.sparsify()
+    assert p.sparse_shape == (fx["room_gc"].max(0) + 96).tolist() and sp.batch_size == len(fx["room_offset"])
+    assert sp.indices.dtype == torch.int32 and np.array_equal(sp.indices[:, 1:].cpu().numpy(), fx["room_gc"])
+    assert np.array_equal(sp.indices[:, 0].cpu().numpy(), oser.offset2batch(fx["room_offset"]))
+    assert sp.replace_feature(p.feat + 1).features.shape == p.feat.shape
+    # a model output carries the plan: the keys follow the level's CURRENT (shuffled) curve order
+    torch.manual_seed(5)
+    q = Point(grid_coord=gc, offset=dev(fx["room_offset"])).serialization(order=ORD, shuffle_orders=True)
+    perm = q.plan.levels[0].curves
+    assert sorted(perm) == [0, 1, 2, 3] and np.array_equal(q.serialized_code.cpu().numpy(), fx["room_code"][perm])
+    assert np.array_equal(q.serialized_order.cpu().numpy(), fx["room_order"][perm])
+    # padding(): the reference's (pad, unpad, cu_seqlens) for every case of the fixture
+    fp = np.load(os.path.join(golden_dir, "padding.npz"))
+    for ci in range(int(fp["ncases"])):
+        offs, K = fp[f"c{ci}_offset"], int(fp[f"c{ci}_K"])
+        n = int(offs[-1])
+        g = torch.Generator().manual_seed(ci)
+        gcc = torch.stack([torch.randperm(n, generator=g), torch.zeros(n, dtype=torch.long), torch.zeros(n, dtype=torch.long)], 1)
+        pt = Point(grid_coord=gcc.cuda(), offset=dev(offs)).serialization(order=("z", "hilbert"))
+        for j in range(2):
+            pad, unpad, cu = pt.padding(K, j)
+            assert np.array_equal(pad.cpu().numpy(), fp[f"c{ci}_pad"]), ci
+            assert np.array_equal(unpad.cpu().numpy(), fp[f"c{ci}_unpad"]), ci
+            assert cu.dtype == torch.int32 and np.array_equal(cu.cpu().numpy(), fp[f"c{ci}_cu"]), ci

@@ -56,3 +56,45 @@ def test_stage_labels_follow_the_backward_order_of_pt_v3m1_names():
     assert default_stage_of("backbone.embedding.stem.conv.weight") == "embedding"
     assert default_stage_of("enc.enc0.block0.cpe.0.weight") == "enc.enc0"
     assert default_stage_of("criteria.0.temperature") == "other"
+
+
+def test_point_batch_offset_helpers_on_the_cpu():
+    """Point derives batch <-> offset lazily (structure.py:41-45 of the reference; values as models/utils/misc.py:11-28)."""
+    import numpy as np
+    import torch
+    from scenesplat_amd.pointcept_api.structure import Point, batch2offset, offset2batch, offset2bincount
+    off = torch.tensor([3, 3, 10, 11])                       # an empty element in the middle
+    assert offset2bincount(off).tolist() == [3, 0, 7, 1]
+    b = offset2batch(off)
+    assert b.dtype == torch.int64 and b.tolist() == np.repeat([0, 1, 2, 3], [3, 0, 7, 1]).tolist()
+    assert batch2offset(b).tolist() == [3, 3, 10, 11]
+    p = Point(offset=off)
+    assert p.batch.tolist() == b.tolist() and "batch" in p
+    q = Point(batch=b)
+    assert q["offset"].tolist() == [3, 3, 10, 11]
+    with pytest.raises(AttributeError):
+        Point(feat=torch.zeros(2, 2)).serialized_code        # no plan: nothing to materialise from
+
+
+def test_plan_ahead_bounds_its_retries_and_waits_at_the_sync_gate(monkeypatch):
+    """A detector somebody else left armed for good must end in an error at the consumer, not in a hang; and while the gate is
+    held (steady_state.py holds it for the one eager step it runs under torch's process-wide sync detector) no build starts."""
+    from scenesplat_amd import plan as P
+    monkeypatch.setattr(P, "PLAN_BUILD_MAX_RETRIES", 5)
+    n = []
+
+    def always():
+        n.append(1)
+        raise RuntimeError("called a synchronizing HIP operation")
+    bad = P.PlanAhead(always, depth=1, device=None)
+    with pytest.raises(RuntimeError, match="plan build thread failed"):
+        bad.get()
+    assert len(n) == 6                                            # the first attempt + 5 retries
+    bad.close()
+    built = []
+    with P.HOST_SYNC_GATE:
+        ahead = P.PlanAhead(lambda: built.append(1) or "plan", depth=1, device=None)
+        time.sleep(0.15)
+        assert built == []                                        # parked at the gate
+    assert ahead.get() == "plan"
+    ahead.close()
