@@ -368,7 +368,14 @@ def secondary_lines(log, steps=3):
                                         value=tot / dt, unit="Gaussians/s", ms_per_step=dt / steps * 1e3, steps=steps,
                                         gaussians_per_step=tot / steps, duplicate_rows_last_batch=dups,
                                         vs_variable_size_training_b2=(tot / dt) / out["variable_size_training_b2"]["value"], dtype="bf16")
-        del model
+        # ---- the stress fixture of SURVEY 8d ("uniform-102400": unique voxels uniform in 300 x 300 x 150, ~1-2 neighbours per site,
+        # pooled levels that barely shrink: 102,400 / 99,735 / 81,633 / 26,646): real scenes sit between it and the room
+        from scenesplat_amd.synthetic import uniform_chunk
+        udata = {k: v.cuda() for k, v in uniform_chunk(seed=0).items()}
+        dt = run(model, model, udata, False, "uniform-102400 stress fixture", steps)
+        out["uniform_102400_stress_fixture"] = dict(metric="Gaussians/s encoder fwd+bwd, uniform-102400 stress fixture (NOT the metric workload), eager launches, 1 GPU",
+                                                    value=udata["feat"].shape[0] / dt, unit="Gaussians/s", ms_per_step=dt * 1e3, steps=steps, dtype="bf16")
+        del model, udata
         gc.collect(); torch.cuda.empty_cache()
         # ---- BASELINE config 5 end to end: 1,000,000-Gaussian region -> LangPretrainer.eval()(input, chunk_size=600000) (the call
         # form of engines/test.py:329-351 / evaluator.py:762) -> 160-label feature x text scan
@@ -397,6 +404,64 @@ def secondary_lines(log, steps=3):
         out["error"] = "%s: %s" % (type(e).__name__, e)
     finally:
         RUNTIME.clear(); RUNTIME.update(old)
+    return out
+
+
+def pointops_lines(log):
+    """Secondary lines for the libs/pointops* replacements (round 4): queries/s and achieved GB/s of the kernels behind
+    knn_query / ball_query / farthest_point_sampling / grouping and the evaluator's neighbour voting (evaluator.py:697-739), on room
+    clouds of 102,400 and 1,000,000 Gaussians.  Timed with CUDA events on the current stream, 3 repetitions, best."""
+    from scenesplat_amd import pointops as po
+    from scenesplat_amd.synthetic import room_chunk
+    out = {}
+
+    def best_ms(fn, reps=3):
+        fn(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record(); torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return min(ts)
+    try:
+        small = room_chunk(256, 0, lang_dim=0)["coord"].cuda().contiguous()
+        big = room_chunk(800, 2, lang_dim=0)["coord"].cuda().contiguous()
+        for name, xyz in (("102400", small), ("1000000", big)):
+            n = xyz.shape[0]
+            off = torch.tensor([n], dtype=torch.int32, device="cuda")
+            ms = best_ms(lambda: po.knn_query(25, xyz, off, impl="grid"))
+            out["knn_k25_grid_%s" % name] = dict(ms=ms, queries_per_s=n / ms * 1e3, what="exact kNN, k = 25, self query, hash-grid ring search incl. grid build (csrc/knn_grid.hip)")
+            log("pointops: knn k=25 grid, n=%s: %.2f ms (%.1f M queries/s)" % (name, ms, n / ms / 1e3))
+        n = small.shape[0]
+        off = torch.tensor([n], dtype=torch.int32, device="cuda")
+        ms = best_ms(lambda: po.knn_query(25, small, off, impl="brute"), reps=2)
+        out["knn_k25_brute_102400"] = dict(ms=ms, queries_per_s=n / ms * 1e3, what="the reference's algorithm (O(m n) scan, LDS-tiled): %.1f G distance evaluations/s" % (n * n / ms / 1e6))
+        log("pointops: knn k=25 brute force, n=102400: %.2f ms" % ms)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        nb = big.shape[0]
+        lab = torch.randint(0, 160, (nb,), device="cuda", generator=g).int()
+        val = torch.rand(nb, device="cuda", generator=g) < 0.9
+        ms = best_ms(lambda: po.neighbor_voting(big, lab, val, 25, -1, 160))
+        out["neighbor_voting_1m_k25"] = dict(ms=ms, gaussians_per_s=nb / ms * 1e3, what="evaluator.py:697-739: kNN (k = 25) among the 90 % valid Gaussians for all 1,000,000 + majority vote (reference: CPU cKDTree + numba)")
+        log("pointops: neighbor voting, 1,000,000 Gaussians, k=25: %.2f ms" % ms)
+        ms = best_ms(lambda: po.ball_query(16, 0.1, 0.0, small, off), reps=2)
+        out["ball_query_16_r0.1_102400"] = dict(ms=ms, queries_per_s=n / ms * 1e3, what="ball_query nsample 16, radius 0.1 m (brute-force scan with per-query candidate scratch)")
+        noff = torch.tensor([n // 4], dtype=torch.int32, device="cuda")
+        ms = best_ms(lambda: po.farthest_point_sampling(small, off, noff), reps=1)
+        out["fps_102400_to_25600"] = dict(ms=ms, samples_per_s=(n // 4) / ms * 1e3, what="farthest point sampling 102,400 -> 25,600 (one workgroup per batch element, sequential by definition)")
+        idx, _ = po.knn_query(16, small, off, impl="grid")
+        feat = torch.randn(n, 64, device="cuda", generator=g).requires_grad_(True)
+        grp = po.grouping2(feat, idx)
+        go = torch.randn_like(grp)
+        ms_f = best_ms(lambda: po.grouping2(feat, idx))
+        ms_b = best_ms(lambda: torch.autograd.grad(po.grouping2(feat, idx), feat, go)) - ms_f
+        by = n * 16 * 64 * 4
+        out["grouping_16x64_102400"] = dict(fwd_ms=ms_f, fwd_GBps=(by + n * 64 * 4) / ms_f / 1e6, bwd_ms=ms_b, bwd_GBps=(by + n * 64 * 4) / max(ms_b, 1e-3) / 1e6,
+                                            what="grouping (gather of 16 neighbour rows of 64 fp32 channels) forward / backward (fp32 atomics)")
+        log("pointops: ball %.2f ms, fps %.1f ms, grouping fwd %.3f / bwd %.3f ms" % (out["ball_query_16_r0.1_102400"]["ms"], out["fps_102400_to_25600"]["ms"], ms_f, ms_b))
+    except Exception as e:  # noqa: BLE001  (secondary lines must never take the headline down)
+        log("pointops lines: %s: %s" % (type(e).__name__, e))
+        out["error"] = "%s: %s" % (type(e).__name__, e)
     return out
 
 
@@ -677,6 +742,7 @@ def main():
             gc.collect(); torch.cuda.empty_cache()
             if not args.no_secondary:
                 res["secondary"] = secondary_lines(log)
+                res["secondary"]["pointops"] = pointops_lines(log)
             if not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(args.cpu_n_side, log)
         sys.stdout.flush()

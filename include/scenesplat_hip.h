@@ -365,6 +365,23 @@ int ss_rpe_dot_prod_fwd(int n, int m, int h, int hdim, const float* q, const int
 int ss_rpe_dot_prod_bwd(int n, int m, int h, int hdim, const float* grad_out, const float* q, const int32_t* index, const float* table, const int32_t* rel_idx, float* grad_q, float* grad_table, ss_stream_t stream);
 int ss_rpe_attn_step2_fwd(int n, int m, int h, int hdim, const float* attn, const float* v, const int32_t* index0, const int32_t* index1, const float* table, const int32_t* rel_idx, float* output, ss_stream_t stream);
 int ss_rpe_attn_step2_bwd(int n, int m, int h, int hdim, const float* grad_out, const int32_t* index0, const int32_t* index1, const float* attn, const float* v, const float* table, const int32_t* rel_idx, float* grad_attn, float* grad_v, float* grad_table, ss_stream_t stream);
+/* Exact kNN on a uniform hash grid (csrc/knn_grid.hip): the result of ss_knn_query -- libs/pointops/src/knn_query/
+ * knn_query_cuda_kernel.cu:60-104, called by the zero-shot evaluator's neighbour voting with k = 25 over ~10^6 Gaussians
+ * (pointcept/engines/hooks/evaluator.py:697-739; the reference runs scipy's cKDTree on the CPU there) -- without the O(m n) scan.
+ *   1. ss_knn_grid_keys      keys[i] = batch << 48 | cx << 32 | cy << 16 | cz, cell = floor((p - origin) / cell_size) clamped to 16 bits
+ *   2. ss_argsort_i64        (sorted keys, order)
+ *   3. ss_knn_grid_build     workspace <- hash table key -> [start, end) + the points in cell order; ncell (1) = occupied cells
+ *   4. ss_knn_grid_query     one wave per query, rings of cells until the k-th distance is inside the searched region; nsample <= 64.
+ * qorder (m) or NULL = processing order of the queries; dim* = the largest cell index of the data per axis. */
+int64_t ss_knn_grid_table_size(int64_t n);
+size_t ss_knn_grid_workspace_bytes(int64_t n);
+int ss_knn_grid_keys(const float* xyz, const int32_t* offset, int num_batches, int64_t n, float origin_x, float origin_y, float origin_z,
+                     float cell_size, int64_t* keys, ss_stream_t stream);
+int ss_knn_grid_build(const float* xyz, const int64_t* sorted_keys, const int32_t* order, int64_t n, void* workspace,
+                      size_t workspace_bytes, int32_t* ncell, ss_stream_t stream);
+int ss_knn_grid_query(int m, int nsample, const float* new_xyz, const int32_t* qorder, const int32_t* offset, const int32_t* new_offset,
+                      int num_batches, float origin_x, float origin_y, float origin_z, float cell_size, int dimx, int dimy, int dimz,
+                      int64_t n, const void* workspace, int32_t* idx, float* dist2, ss_stream_t stream);
 /* neighbour majority vote of the zero-shot evaluator (pointcept/utils/misc.py:17-51): ties -> smallest label, k <= 64 */
 int ss_majority_vote(const int32_t* nn_idx, const int32_t* labels, int64_t m, int k, int ignore_label, int num_classes,
                      int32_t* out, ss_stream_t stream);

@@ -1,0 +1,301 @@
+// Exact k-nearest-neighbour search on a uniform hash grid (gfx950), round 4.
+//
+// Replaces the O(m n) brute-force scan of ss_knn_query (libs/pointops/src/knn_query/knn_query_cuda_kernel.cu:60-104 is the same
+// scan) where it matters: the zero-shot evaluator's neighbour voting (pointcept/engines/hooks/evaluator.py:697-739,
+// pointcept/utils/misc.py:54-95: cKDTree.query(k = 25) over ~10^6 valid Gaussians = 10^12 distance evaluations brute force).
+// Same result as the brute-force kernel -- the k nearest candidates of the query's batch element, ascending, -1 / 1e10 padding,
+// the SAME fp32 distance expression (po_dist2) -- found by expanding rings of grid cells around the query until the k-th best
+// distance is provably inside the searched region.
+//
+//   build   cell key = batch << 48 | cx << 32 | cy << 16 | cz   (cell = floor((p - origin) / h), 16 bits per axis)
+//           stable radix argsort of the keys (ss_argsort_i64, the plan's sort) -> points in cell order, copied next to each other
+//           as float4 (x, y, z, original index); an open-addressing hash table  key -> [start, end)  of the sorted positions
+//   query   ONE WAVE per query: the 64 lanes probe the cells of a ring in parallel, the points of the occupied cells are
+//           flattened over the lanes (prefix sum + binary search in LDS), the running top-k is a sorted list held one entry per
+//           lane (k <= 64): a batch of candidates is either inserted one by one (few survive the k-th-best threshold) or merged
+//           by a bitonic sort + merge across the wave.  No heap in scratch memory, no divergence between the queries of a wave.
+//   stop    after ring r every unseen point is farther than r h + (distance of the query to the nearest face of its own cell).
+//           Rings beyond SS_KNN_RING_MAX fall back to a wave-wide scan of the batch element (sparse outliers), so the worst case per
+//           query is the brute-force cost spread over 64 lanes.
+#include "common.h"
+#include "../../include/scenesplat_hip.h"
+
+#define KG_THREADS 256
+#define KG_WAVES (KG_THREADS / 64)
+#define KG_RING_MAX 6
+#define KG_INF 3.0e38f
+
+struct __attribute__((aligned(16))) KgCell { long long key; int start; int end; };
+
+__device__ __forceinline__ float po_dist2(float qx, float qy, float qz, float x, float y, float z) {
+  const float dx = qx - x, dy = qy - y, dz = qz - z;
+  return dx * dx + dy * dy + dz * dz;
+}
+
+__device__ __forceinline__ unsigned kg_hash(long long k) {
+  unsigned long long x = (unsigned long long)k;
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return (unsigned)x;
+}
+
+__device__ __forceinline__ int kg_batch_of(int i, const int32_t* __restrict__ offset, int nb) {
+  int lo = 0, hi = nb;   // first b with offset[b] > i
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (offset[mid] <= i) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+__device__ __forceinline__ int kg_cell(float p, float origin, float inv_h) { return (int)floorf((p - origin) * inv_h); }
+
+// keys of n points (cells clamped into [0, 65535]: the caller sizes h so that the grid of the data fits)
+__global__ void k_kg_keys(const float* __restrict__ xyz, const int32_t* __restrict__ offset, int nb, int n, float ox, float oy, float oz,
+                          float inv_h, long long* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long b = kg_batch_of(i, offset, nb);
+  const int cx = min(65535, max(0, kg_cell(xyz[3 * i], ox, inv_h))), cy = min(65535, max(0, kg_cell(xyz[3 * i + 1], oy, inv_h)));
+  const int cz = min(65535, max(0, kg_cell(xyz[3 * i + 2], oz, inv_h)));
+  keys[i] = (b << 48) | ((long long)cx << 32) | ((long long)cy << 16) | (long long)cz;
+}
+
+__global__ void k_kg_clear(KgCell* __restrict__ table, int size) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < size) { table[i].key = -1; table[i].start = 0; table[i].end = 0; }
+}
+
+// sorted position p: copy the point next to its cell mates; run heads claim a table slot and write `start`, run tails write `end`
+// (a tail finds the slot its head claimed: heads and tails of one launch may race, so tails run in a second launch)
+__global__ void k_kg_heads(const float* __restrict__ xyz, const long long* __restrict__ skeys, const int32_t* __restrict__ order, int n,
+                           KgCell* __restrict__ table, unsigned mask, float4* __restrict__ pts, int32_t* __restrict__ ncell) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int head = 0;
+  if (p < n) {
+    const int src = order[p];
+    pts[p] = make_float4(xyz[3 * src], xyz[3 * src + 1], xyz[3 * src + 2], __int_as_float(src));
+    const long long key = skeys[p];
+    if (p == 0 || skeys[p - 1] != key) {
+      head = 1;
+      unsigned h = kg_hash(key) & mask;
+      while (true) {
+        const long long prev = (long long)atomicCAS((unsigned long long*)&table[h].key, (unsigned long long)-1LL, (unsigned long long)key);
+        if (prev == -1LL) { table[h].start = p; break; }
+        h = (h + 1) & mask;                      // keys of heads are distinct: an occupied slot belongs to another cell
+      }
+    }
+  }
+  const unsigned long long m = __ballot(head);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(ncell, __popcll(m));
+}
+
+__global__ void k_kg_tails(const long long* __restrict__ skeys, int n, KgCell* __restrict__ table, unsigned mask) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const long long key = skeys[p];
+  if (p + 1 < n && skeys[p + 1] == key) return;
+  unsigned h = kg_hash(key) & mask;
+  while (table[h].key != key) h = (h + 1) & mask;
+  table[h].end = p + 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// the running top-k of a wave: lane i < k holds the i-th smallest (d, idx) seen so far, lanes >= k hold +inf
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool kg_less(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
+
+// bitonic sort of one (d, i) pair per lane, ascending over the lanes
+__device__ __forceinline__ void kg_sort64(float& d, int& i, int lane) {
+#pragma unroll
+  for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const float pd = __shfl_xor(d, stride, 64); const int pi = __shfl_xor(i, stride, 64);
+      const bool up = (lane & size) == 0, low = (lane & stride) == 0;
+      const bool take_min = (low == up);
+      const bool p_less = kg_less(pd, pi, d, i);
+      if (take_min == p_less) { d = pd; i = pi; }
+    }
+  }
+}
+
+// merge a batch (one candidate per lane, +inf where none) into the list: sort the batch descending-by-lane, keep the lane-wise
+// minimum of list and batch (the 64 smallest of the union, a bitonic sequence), sort that sequence with one bitonic merge
+__device__ __forceinline__ void kg_merge64(float& bd, int& bi, float cd, int ci, int lane, int k) {
+  kg_sort64(cd, ci, lane);
+  const float rd = __shfl(cd, 63 - lane, 64); const int ri = __shfl(ci, 63 - lane, 64);       // descending over the lanes
+  if (kg_less(rd, ri, bd, bi)) { bd = rd; bi = ri; }
+#pragma unroll
+  for (int stride = 32; stride > 0; stride >>= 1) {
+    const float pd = __shfl_xor(bd, stride, 64); const int pi = __shfl_xor(bi, stride, 64);
+    const bool low = (lane & stride) == 0;
+    const bool p_less = kg_less(pd, pi, bd, bi);
+    if (low == p_less) { bd = pd; bi = pi; }
+  }
+  if (lane >= k) { bd = KG_INF; bi = -1; }
+}
+
+// one candidate batch: d2 / oi per lane (act = the lane holds one)
+__device__ __forceinline__ void kg_offer(float& bd, int& bi, float d2, int oi, bool act, int lane, int k) {
+  const float thr = __shfl(bd, k - 1, 64);
+  unsigned long long m = __ballot(act && d2 < thr);
+  if (!m) return;
+  if (__popcll(m) > 6) {
+    kg_merge64(bd, bi, (act && d2 < thr) ? d2 : KG_INF, (act && d2 < thr) ? oi : -1, lane, k);
+    return;
+  }
+  while (m) {
+    const int j = __builtin_ctzll(m); m &= m - 1;
+    const float cd = __shfl(d2, j, 64); const int ci = __shfl(oi, j, 64);
+    if (!(cd < __shfl(bd, k - 1, 64))) continue;
+    // position = number of list entries that sort before the candidate
+    const int pos = __popcll(__ballot(kg_less(bd, bi, cd, ci)));
+    const float ud = __shfl_up(bd, 1, 64); const int ui = __shfl_up(bi, 1, 64);
+    if (lane > pos) { bd = ud; bi = ui; }
+    if (lane == pos) { bd = cd; bi = ci; }
+    if (lane >= k) { bd = KG_INF; bi = -1; }
+  }
+}
+
+__global__ void __launch_bounds__(KG_THREADS)
+k_kg_query(int m, int k, const float* __restrict__ new_xyz, const int32_t* __restrict__ qorder, const int32_t* __restrict__ offset,
+           const int32_t* __restrict__ new_offset, int nb, float ox, float oy, float oz, float h, float inv_h, int dimx, int dimy, int dimz,
+           const KgCell* __restrict__ table, unsigned mask, const float4* __restrict__ pts, int32_t* __restrict__ idx,
+           float* __restrict__ dist2) {
+  __shared__ int pre_s[KG_WAVES][64];
+  __shared__ int start_s[KG_WAVES][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int w = blockIdx.x * KG_WAVES + wv;
+  if (w >= m) return;                                                   // wave-uniform
+  const int q = qorder ? qorder[w] : w;
+  const float qx = new_xyz[3 * q], qy = new_xyz[3 * q + 1], qz = new_xyz[3 * q + 2];
+  const int b = kg_batch_of(q, new_offset, nb);
+  const int seg0 = b == 0 ? 0 : offset[b - 1], seg1 = offset[b];
+  const int cx = kg_cell(qx, ox, inv_h), cy = kg_cell(qy, oy, inv_h), cz = kg_cell(qz, oz, inv_h);
+  // distance of the query to the nearest face of its own cell (cells tile all of space, also outside the data's box)
+  const float fx = (qx - ox) - (float)cx * h, fy = (qy - oy) - (float)cy * h, fz = (qz - oz) - (float)cz * h;
+  // (minus a slack for the rounding of floor((p - origin) / h): a point next to a cell face may be keyed one cell over)
+  const float slack = 1e-3f * h + 1e-6f * (fabsf(qx - ox) + fabsf(qy - oy) + fabsf(qz - oz));
+  const float margin = fminf(fminf(fminf(fx, h - fx), fminf(fy, h - fy)), fminf(fz, h - fz)) - slack;
+  // rings below r0 hold no cell of the data's box; beyond r1 there is none left
+  const int r0 = max(0, max(max(max(-cx, cx - dimx), max(-cy, cy - dimy)), max(-cz, cz - dimz)));
+  const int r1 = max(max(max(abs(cx), abs(cx - dimx)), max(abs(cy), abs(cy - dimy))), max(abs(cz), abs(cz - dimz)));
+  float bd = KG_INF; int bi = -1;
+  bool done = false;
+  for (int r = r0; r <= r1 && !done; ++r) {
+    if (r - r0 > KG_RING_MAX) {
+      // sparse neighbourhood: scan the rest of the batch element wave-wide.  Points of rings < r were offered already; offering
+      // them again would duplicate entries, so they are skipped by their cell distance.
+      for (int p0 = seg0; p0 < seg1; p0 += 64) {
+        const int p = p0 + lane; const bool act = p < seg1;
+        float d2 = KG_INF; int oi = -1; bool fresh = false;
+        if (act) {
+          const float4 pt = pts[p];
+          const int pcx = min(65535, max(0, kg_cell(pt.x, ox, inv_h))), pcy = min(65535, max(0, kg_cell(pt.y, oy, inv_h)));
+          const int pcz = min(65535, max(0, kg_cell(pt.z, oz, inv_h)));
+          fresh = max(max(abs(pcx - cx), abs(pcy - cy)), abs(pcz - cz)) >= r;
+          d2 = po_dist2(qx, qy, qz, pt.x, pt.y, pt.z); oi = __float_as_int(pt.w);
+        }
+        kg_offer(bd, bi, d2, oi, act && fresh, lane, k);
+      }
+      break;
+    }
+    const int side = 2 * r + 1, ncell = side * side * side;
+    for (int base = 0; base < ncell; base += 64) {
+      const int e = base + lane;
+      int cnt = 0, st = 0;
+      if (e < ncell) {
+        const int dx = e / (side * side) - r, rem = e % (side * side), dy = rem / side - r, dz = rem % side - r;
+        const int X = cx + dx, Y = cy + dy, Z = cz + dz;
+        if (max(max(abs(dx), abs(dy)), abs(dz)) == r && X >= 0 && Y >= 0 && Z >= 0 && X <= dimx && Y <= dimy && Z <= dimz) {
+          const long long key = ((long long)b << 48) | ((long long)X << 32) | ((long long)Y << 16) | (long long)Z;
+          unsigned hh = kg_hash(key) & mask;
+          while (true) {
+            const KgCell c = table[hh];
+            if (c.key == key) { st = c.start; cnt = c.end - c.start; break; }
+            if (c.key == -1LL) break;
+            hh = (hh + 1) & mask;
+          }
+        }
+      }
+      if (!__ballot(cnt > 0)) continue;
+      // exclusive prefix sum of the counts over the lanes
+      int inc = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+      const int total = __shfl(inc, 63, 64);
+      pre_s[wv][lane] = inc - cnt; start_s[wv][lane] = st;              // (LDS is in order per wave: no barrier)
+      for (int tt = 0; tt < total; tt += 64) {
+        const int t = tt + lane; const bool act = t < total;
+        float d2 = KG_INF; int oi = -1;
+        if (act) {
+          int lo = 0;
+#pragma unroll
+          for (int s = 32; s > 0; s >>= 1) if (pre_s[wv][lo + s] <= t) lo += s;       // the largest lane whose run starts at or before t
+          // owns t (empty runs before it share its prefix but have smaller lane numbers; every lane after it starts beyond t)
+          const float4 pt = pts[start_s[wv][lo] + (t - pre_s[wv][lo])];
+          d2 = po_dist2(qx, qy, qz, pt.x, pt.y, pt.z); oi = __float_as_int(pt.w);
+        }
+        kg_offer(bd, bi, d2, oi, act, lane, k);
+      }
+    }
+    const float kth = __shfl(bd, k - 1, 64);
+    const float reach = fmaxf(0.f, (float)(r) * h + margin);
+    done = kth <= reach * reach * 0.9999f;
+  }
+  if (lane < k) {
+    idx[(int64_t)q * k + lane] = bi;
+    dist2[(int64_t)q * k + lane] = bi < 0 ? 1e10f : bd;
+  }
+}
+
+extern "C" int64_t ss_knn_grid_table_size(int64_t n) {
+  int64_t s = 64;
+  while (s < 2 * n) s <<= 1;
+  return s;
+}
+
+// workspace = table (16 B x table_size) + pts (16 B x n); 256-byte aligned pieces
+extern "C" size_t ss_knn_grid_workspace_bytes(int64_t n) {
+  return (size_t)(16 * ss_knn_grid_table_size(n) + 16 * ((n + 15) / 16 * 16) + 512);
+}
+
+extern "C" int ss_knn_grid_keys(const float* xyz, const int32_t* offset, int num_batches, int64_t n, float ox, float oy, float oz,
+                                float cell, int64_t* keys, hipStream_t stream) {
+  if (n < 0 || n >= (1LL << 31) || num_batches < 1 || num_batches > 32767 || !(cell > 0.f)) return SS_ERR_ARG;
+  if (n == 0) return SS_OK;
+  SS_LAUNCH(k_kg_keys, dim3(ss_div_up(n, 256)), dim3(256), 0, stream, xyz, offset, num_batches, (int)n, ox, oy, oz, 1.0f / cell,
+            (long long*)keys);
+  return SS_OK;
+}
+
+// sorted_keys / order: ss_argsort_i64 of the keys.  ncell (1) device int = number of occupied cells (the caller may read it to tune h).
+extern "C" int ss_knn_grid_build(const float* xyz, const int64_t* sorted_keys, const int32_t* order, int64_t n, void* workspace,
+                                 size_t workspace_bytes, int32_t* ncell, hipStream_t stream) {
+  if (n < 0 || n >= (1LL << 31) || ((uintptr_t)workspace & 15) || workspace_bytes < ss_knn_grid_workspace_bytes(n)) return SS_ERR_ARG;
+  const int64_t ts = ss_knn_grid_table_size(n);
+  KgCell* table = (KgCell*)workspace;
+  float4* pts = (float4*)((char*)workspace + 16 * ts);
+  (void)hipMemsetAsync(ncell, 0, sizeof(int32_t), stream);
+  SS_LAUNCH(k_kg_clear, dim3(ss_div_up(ts, 256)), dim3(256), 0, stream, table, (int)ts);
+  if (n == 0) return SS_OK;
+  SS_LAUNCH(k_kg_heads, dim3(ss_div_up(n, 256)), dim3(256), 0, stream, xyz, (const long long*)sorted_keys, order, (int)n, table,
+            (unsigned)(ts - 1), pts, ncell);
+  SS_LAUNCH(k_kg_tails, dim3(ss_div_up(n, 256)), dim3(256), 0, stream, (const long long*)sorted_keys, (int)n, table, (unsigned)(ts - 1));
+  return SS_OK;
+}
+
+// idx (m, nsample) int32 / dist2 (m, nsample) f32 as ss_knn_query; nsample <= 64.  qorder (m) or NULL: the order in which the
+// queries are processed (cell order keeps the probes of consecutive waves in the same L2 lines); dims = the largest cell index of
+// the data per axis.
+extern "C" int ss_knn_grid_query(int m, int nsample, const float* new_xyz, const int32_t* qorder, const int32_t* offset,
+                                 const int32_t* new_offset, int num_batches, float ox, float oy, float oz, float cell, int dimx, int dimy,
+                                 int dimz, int64_t n, const void* workspace, int32_t* idx, float* dist2, hipStream_t stream) {
+  if (m < 0 || nsample < 1 || nsample > 64 || num_batches < 1 || n < 0 || !(cell > 0.f) || dimx < 0 || dimy < 0 || dimz < 0 ||
+      dimx > 65535 || dimy > 65535 || dimz > 65535)
+    return SS_ERR_ARG;
+  if (m == 0) return SS_OK;
+  const int64_t ts = ss_knn_grid_table_size(n);
+  const KgCell* table = (const KgCell*)workspace;
+  const float4* pts = (const float4*)((const char*)workspace + 16 * ts);
+  SS_LAUNCH(k_kg_query, dim3(ss_div_up(m, KG_WAVES)), dim3(KG_THREADS), 0, stream, m, nsample, new_xyz, qorder, offset, new_offset,
+            num_batches, ox, oy, oz, cell, 1.0f / cell, dimx, dimy, dimz, table, (unsigned)(ts - 1), pts, idx, dist2);
+  return SS_OK;
+}

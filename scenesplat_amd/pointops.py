@@ -37,18 +37,81 @@ def batch2offset(batch):
 
 
 # ---- queries -----------------------------------------------------------------------------------
-def knn_query(nsample, xyz, offset, new_xyz=None, new_offset=None):
-    """-> idx (m, nsample) int32 (-1 pad), dist (m, nsample) f32 (sqrt of squared distance)."""
-    if new_xyz is None or new_offset is None:
+KNN_GRID_MIN_POINTS = 4096       # below: the brute-force scan (one LDS tile pass) is faster than building a grid
+
+
+def knn_query(nsample, xyz, offset, new_xyz=None, new_offset=None, impl="auto"):
+    """-> idx (m, nsample) int32 (-1 pad), dist (m, nsample) f32 (sqrt of squared distance).
+    impl: "brute" = the O(m n) LDS-tiled scan (the reference's algorithm, knn_query_cuda_kernel.cu:60-104); "grid" = the exact
+    ring search on a uniform hash grid (csrc/knn_grid.hip, nsample <= 64); "auto" = grid from KNN_GRID_MIN_POINTS candidates on.
+    Both return the same neighbours (same fp32 distance expression; equal distances: the smaller index first)."""
+    self_query = new_xyz is None or new_offset is None
+    if self_query:
         new_xyz, new_offset = xyz, offset
     xyz, new_xyz = _f(xyz, "xyz"), _f(new_xyz, "new_xyz")
     off, noff = _i(offset, "offset"), _i(new_offset, "new_offset")
     m = new_xyz.shape[0]
+    if impl == "grid" or (impl == "auto" and nsample <= 64 and xyz.shape[0] >= KNN_GRID_MIN_POINTS):
+        if nsample > 64:
+            raise RuntimeError("knn_query: the grid search holds one list entry per lane (nsample <= 64)")
+        idx, d2 = _knn_grid(nsample, xyz, off, new_xyz, noff, self_query)
+        return idx, torch.sqrt(d2)
     idx = torch.empty((m, nsample), dtype=torch.int32, device=xyz.device)
     d2 = torch.empty((m, nsample), dtype=torch.float32, device=xyz.device)
     check(nv.lib().ss_knn_query(m, nsample, _p(xyz), _p(new_xyz), _p(off), _p(noff), off.numel(), _p(idx), _p(d2), _s()),
           "ss_knn_query")
     return idx, torch.sqrt(d2)
+
+
+def _knn_grid(nsample, xyz, off, new_xyz, noff, self_query, cell=None, return_info=False):
+    """Build the hash grid over xyz (cell size from the data: ~2/3 nsample points per OCCUPIED cell, refined at most twice from
+    the occupied-cell count the build reports) and run the ring search.  Host reads: the bounding box and that count."""
+    import ctypes
+    n, m, dev = xyz.shape[0], new_xyz.shape[0], xyz.device
+    lib = nv.lib()
+    lo, hi = xyz.amin(0), xyz.amax(0)
+    box = torch.cat([lo, hi]).cpu().tolist()
+    origin, ext = box[:3], [max(box[3 + a] - box[a], 1e-6) for a in range(3)]
+    target = max(4.0, 0.66 * nsample)
+    if cell is None:
+        h = max((ext[0] * ext[1] * ext[2] / max(n, 1) * target) ** (1.0 / 3.0), max(ext) / 60000.0, 1e-6)
+        tries = 3
+    else:
+        h, tries = float(cell), 1
+    ws = nv._ws(lib.ss_knn_grid_workspace_bytes(n), dev)
+    keys = torch.empty((1, n), dtype=torch.int64, device=dev)
+    ncell = torch.empty(1, dtype=torch.int32, device=dev)
+    nb = off.numel()
+    for it in range(tries):
+        check(lib.ss_knn_grid_keys(_p(xyz), _p(off), nb, n, origin[0], origin[1], origin[2], h, _p(keys), _s()), "ss_knn_grid_keys")
+        order, _, skeys = nv.argsort_i64(keys, 63, want_inverse=False)
+        check(lib.ss_knn_grid_build(_p(xyz), _p(skeys), _p(order), n, _p(ws), ws.numel(), _p(ncell), _s()), "ss_knn_grid_build")
+        if it + 1 == tries:
+            break
+        occ = n / max(1, int(ncell.item()))
+        if occ > 1.6 * target:         # surfaces: occupancy grows with h^2
+            h2 = h * max(0.25, (target / occ) ** 0.5)
+        elif occ < 0.4 * target:
+            h2 = h * min(4.0, (target / occ) ** (1.0 / 3.0))
+        else:
+            break
+        h2 = max(h2, max(ext) / 60000.0)
+        if abs(h2 - h) < 1e-3 * h:
+            break
+        h = h2
+    dims = [min(65535, int(ext[a] / h) + 1) for a in range(3)]
+    qorder = order[0]
+    if not self_query:
+        qkeys = torch.empty((1, m), dtype=torch.int64, device=dev)
+        check(lib.ss_knn_grid_keys(_p(new_xyz), _p(noff), noff.numel(), m, origin[0], origin[1], origin[2], h, _p(qkeys), _s()), "ss_knn_grid_keys")
+        qorder = nv.argsort_i64(qkeys, 63, want_inverse=False, want_sorted=False)[0][0]
+    idx = torch.empty((m, nsample), dtype=torch.int32, device=dev)
+    d2 = torch.empty((m, nsample), dtype=torch.float32, device=dev)
+    check(lib.ss_knn_grid_query(m, nsample, _p(new_xyz), _p(qorder), _p(off), _p(noff), nb, origin[0], origin[1], origin[2], h,
+                                dims[0], dims[1], dims[2], n, _p(ws), _p(idx), _p(d2), _s()), "ss_knn_grid_query")
+    if return_info:
+        return idx, d2, dict(cell=h, dims=dims, occupied_cells=int(ncell.item()), points_per_cell=n / max(1, int(ncell.item())))
+    return idx, d2
 
 
 def ball_query(nsample, max_radius, min_radius, xyz, offset, new_xyz=None, new_offset=None):

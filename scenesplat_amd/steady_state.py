@@ -123,6 +123,11 @@ class SteadyStateStep:
                     elif not on and armed[0]:
                         torch.cuda.set_sync_debug_mode("default"); HOST_SYNC_GATE.release(); armed[0] = False
                 arm(True)
+                # torch reports a stale AccumulateGrad node with a warn-ONCE warning: once per process unless warn_always is on, and a
+                # capture that runs into such a node pulls the default stream into the capture -- ending that capture crashes inside the
+                # runtime (seen: segmentation fault in capture_end).  Every checked step must see the warning, not only the first one.
+                warn_always = torch.is_warn_always_enabled()
+                torch.set_warn_always(True)
                 try:
                     with warnings.catch_warnings(record=True) as seen, torch.cuda.stream(side):
                         warnings.simplefilter("always")
@@ -140,6 +145,7 @@ class SteadyStateStep:
                     return self._eager(plan, inputs)
                 finally:
                     arm(False)
+                    torch.set_warn_always(warn_always)
             try:
                 cap = self._capture(plan, inputs)
             except CaptureInvalidated as e:

@@ -249,3 +249,73 @@ def test_pointops2_v2_v3_call_forms():
     o5 = po.attention_step2_with_rel_pos_value_v2(cu(attn), cu(v), cu(offs, torch.int32), n_max, cu(i1, torch.int32), cu(tq_),
                                                   cu(rel, torch.int32))
     assert np.allclose(o5.cpu().numpy(), opo.rpe_attn_step2(attn, v, i0, i1, tq_, rel, n), atol=1e-4)
+
+
+# ---- exact kNN on the hash grid (csrc/knn_grid.hip) against the brute-force kernel ---------------------------------------------
+def _room_cloud(n_side, seed, batch=1):
+    from scenesplat_amd.synthetic import room_chunk
+    d = room_chunk(n_side, seed, lang_dim=0, batch=batch)
+    return d["coord"].numpy().astype(np.float32), d["offset"].numpy()
+
+
+@pytest.mark.parametrize("case", ["uniform", "room2", "queries_outside", "k_exceeds_segment", "outliers", "k1", "k64"])
+def test_knn_grid_equals_the_brute_force_kernel(case):
+    """The ring search returns the brute-force kernel's neighbours bit for bit -- indices AND squared distances (same fp32
+    distance expression) -- on volumetric and surface clouds, several batch elements, queries outside the data's box, segments with
+    fewer than k points (-1 padding) and isolated outliers (the wave-wide fallback scan)."""
+    from scenesplat_amd import pointops as po
+    g = np.random.default_rng(7)
+    k, new_xyz, noff = 25, None, None
+    if case == "uniform":
+        xyz = g.random((20000, 3), dtype=np.float32) * np.array([4.0, 3.0, 2.0], np.float32); off = np.array([12000, 20000])
+    elif case == "room2":
+        xyz, off = _room_cloud(96, 1, batch=2)
+    elif case == "queries_outside":
+        xyz, off = _room_cloud(64, 2)
+        new_xyz = np.concatenate([xyz[:3000] + 0.01, g.random((500, 3), dtype=np.float32) * 8 - 3]).astype(np.float32)
+        noff = np.array([len(new_xyz)])
+    elif case == "k_exceeds_segment":
+        xyz = g.random((6000, 3), dtype=np.float32); off = np.array([5980, 6000]); k = 40          # the second element holds 20 points
+    elif case == "outliers":
+        xyz, off = _room_cloud(64, 3)
+        xyz = np.concatenate([xyz, np.array([[40, 40, 40], [-30, 2, 1], [2, 55, -9]], np.float32)]); off = np.array([len(xyz)])
+    elif case == "k1":
+        xyz, off = _room_cloud(64, 4); k = 1
+    else:
+        xyz = g.random((9000, 3), dtype=np.float32); off = np.array([9000]); k = 64
+    args = (cu(xyz), cu(off)) + (() if new_xyz is None else (cu(new_xyz), cu(noff)))
+    bi, bd = po.knn_query(k, *args, impl="brute")
+    gi, gd = po.knn_query(k, *args, impl="grid")
+    assert torch.equal(gi, bi), (case, int((gi != bi).sum()))
+    assert torch.equal(gd, bd)
+    if case == "k_exceeds_segment":
+        assert bool((gi[5980:, 20:] == -1).all()) and bool((gi[5980:, :20] >= 5980).all())
+    # "auto" picks the grid from KNN_GRID_MIN_POINTS candidates on
+    ai, _ = po.knn_query(k, *args)
+    assert torch.equal(ai, bi)
+
+
+def test_neighbor_voting_on_the_grid_matches_brute_force_and_scales():
+    """evaluator.py:697-739 (k = 25 over the valid Gaussians, all Gaussians queried): same labels through either kNN; and the
+    1,000,000-Gaussian case the review asks for runs (timing is reported by bench.py's secondary line, not asserted here)."""
+    from scenesplat_amd import pointops as po
+    xyz, _ = _room_cloud(160, 5)                       # 40,000 Gaussians
+    n = len(xyz)
+    g = torch.Generator().manual_seed(1)
+    labels = torch.randint(0, 20, (n,), generator=g).int().cuda()
+    valid = (torch.rand(n, generator=g) < 0.9).cuda()
+    a = po.neighbor_voting(cu(xyz), labels, valid, 25, -1, 20)
+    old = po.KNN_GRID_MIN_POINTS
+    try:
+        po.KNN_GRID_MIN_POINTS = 1 << 40
+        b = po.neighbor_voting(cu(xyz), labels, valid, 25, -1, 20)
+    finally:
+        po.KNN_GRID_MIN_POINTS = old
+    assert torch.equal(a, b)
+    big, _ = _room_cloud(800, 6)                        # 1,000,000 Gaussians
+    nb = len(big)
+    lab = torch.randint(0, 160, (nb,), generator=g).int().cuda()
+    val = (torch.rand(nb, generator=g) < 0.9).cuda()
+    out = po.neighbor_voting(cu(big), lab, val, 25, -1, 160)
+    torch.cuda.synchronize()
+    assert out.shape == (nb,) and int(out.min()) >= 0 and int(out.max()) < 160

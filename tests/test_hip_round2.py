@@ -319,6 +319,45 @@ def test_config3_lang_pretrainer_b8_x_102400_one_step():
     assert not bad, bad[:5]
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bench"])
+def test_config3_b8_eval_forward_equals_the_eight_stand_alone_forwards(mode):
+    """Config 3's batch shape: the eval-BN forward of B = 8 chunks x 102,400 Gaussians equals, row for row, the eight stand-alone
+    forwards of its chunks (same weights, same curve permutations) -- the property that proves the batch bits of the codes, the
+    per-element window boundaries and the per-element rulebooks at full size (serialization/default.py:21-23, ptv3:141-164).
+    fp32 mode (per-tap fp32 conv, fp32-math attention): equal to fp32 summation noise.  bench mode (bf16 autocast, MFMA kernels):
+    equal to the run-to-run noise of the bf16 pipeline (tile boundaries move with the batch; fp32 atomics at the small levels)."""
+    from scenesplat_amd import native as nv
+    from scenesplat_amd.pointcept_api import MODELS, bench_runtime
+    from scenesplat_amd.synthetic import LANG_PTV3, room_chunk
+    rt = bench_runtime() if mode == "bench" else dict(attn_impl=nv.ATTN_SIMT, conv_dtype=None)
+    with _Runtime(**rt):
+        torch.manual_seed(0)
+        model = MODELS.build(dict(type="PT-v3m1", **dict(LANG_PTV3, shuffle_orders=False))).cuda().eval()
+        data = room_chunk(n_side=256, seed=0, lang_dim=0, batch=8)
+        offs = [0] + data["offset"].tolist()
+        assert offs[-1] == 8 * 102400
+        perms = [list(range(4)), [2, 0, 3, 1], [1, 3, 0, 2], [3, 2, 1, 0]]
+
+        def fwd(feat, gc, offset):
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=(mode == "bench")):
+                out = model(dict(feat=feat.cuda(), grid_coord=gc.cuda(), offset=offset.cuda()), perms=perms)
+            return out.feat.float(), out["plan"]
+        y8, plan = fwd(data["feat"], data["grid_coord"], data["offset"])
+        assert plan.levels[0].offsets == offs and plan.levels[0].window(0, 1024).num_windows == 800
+        worst = (0.0, 0.0)
+        for i in range(8):
+            a, b = offs[i], offs[i + 1]
+            yi, _ = fwd(data["feat"][a:b], data["grid_coord"][a:b], torch.tensor([b - a]))
+            cd = float((1 - F.cosine_similarity(y8[a:b].double(), yi.double(), dim=1)).max())
+            rel = float((y8[a:b] - yi).norm() / yi.norm())
+            worst = (max(worst[0], cd), max(worst[1], rel))
+        print("config 3 [%s]: B = 8 eval forward vs the 8 stand-alone forwards: max per-row cosine distance %.2e, worst chunk rel %.2e" % ((mode,) + worst))
+        if mode == "fp32":
+            assert worst[0] < 1e-9 and worst[1] < 1e-5, worst
+        else:
+            assert worst[0] < 2e-5 and worst[1] < 5e-3, worst
+
+
 # ---- data parallel on the real model ---------------------------------------------------------------------------
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p

@@ -63,6 +63,13 @@ def _setup(drop_path=0.0, seed=11):
     return model, d, d["feat"].shape[0]
 
 
+def _plain_step(model, d, feat, cot, perms):
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = model(dict(feat=feat, grid_coord=d["grid_coord"], offset=d["offset"], plan=model.prepare_plan(d, perms=perms)))
+    torch.autograd.backward(out.feat, grad_tensors=cot)
+    return out.feat.detach().float().clone()
+
+
 def _grad_err(model, ref):
     num = sum(float((p.grad - ref[k]).norm()) ** 2 for k, p in model.named_parameters()) ** 0.5
     den = sum(float(ref[k].norm()) ** 2 for k in ref) ** 0.5
@@ -85,12 +92,10 @@ def test_backward_cut_two_calls_equal_one_call_eager_and_as_two_graphs():
             feat = torch.randn(n, 11, device="cuda", generator=g)
             cot = torch.randn(n, TINY["dec_channels"][0], device="cuda", generator=g).to(torch.bfloat16)
             perms = model.draw_perms()
-            # reference: the ordinary one-call backward, no cut
+            # reference: the ordinary one-call backward, no cut (nothing of its autograd graph may outlive this block: a captured
+            # step must not meet AccumulateGrad nodes of another stream, steady_state.py)
             model.zero_grad(set_to_none=True)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                out = model(dict(feat=feat, grid_coord=d["grid_coord"], offset=d["offset"], plan=model.prepare_plan(d, perms=perms)))
-            torch.autograd.backward(out.feat, grad_tensors=cot)
-            ref_y = out.feat.detach().float().clone()
+            ref_y = _plain_step(model, d, feat, cot, perms)
             ref = {k: p.grad.clone() for k, p in model.named_parameters()}
             assert all(p.grad is not None for p in model.parameters())
             model.zero_grad(set_to_none=True)
@@ -134,6 +139,7 @@ def _split_worker(rank, world, port, q, mode):
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 out = model(dict(feat=feat, grid_coord=d["grid_coord"], offset=d["offset"], plan=plan))
             torch.autograd.backward(out.feat, grad_tensors=cot)
+            del out
             ex.finish()
         else:
             steady(plan, dict(feat=feat, cot=cot))
@@ -195,9 +201,7 @@ def _rccl_split_worker(port, q):
         cot = torch.randn(n, TINY["dec_channels"][0], device="cuda", generator=g).to(torch.bfloat16)
         perms = model.draw_perms()
         model.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            out = model(dict(feat=feat, grid_coord=d["grid_coord"], offset=d["offset"], plan=model.prepare_plan(d, perms=perms)))
-        torch.autograd.backward(out.feat, grad_tensors=cot)
+        _plain_step(model, d, feat, cot, perms)
         ref = {k: p.grad.clone() for k, p in model.named_parameters()}
         model.zero_grad(set_to_none=True)
         steady(model.prepare_plan(d, perms=perms), dict(feat=feat, cot=cot))
