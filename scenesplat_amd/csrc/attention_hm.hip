@@ -38,11 +38,16 @@ typedef __attribute__((address_space(3))) hs4_t hlds_s4_t;
 #define HM_THREADS (64 * HM_WAVES)
 #define HM_BQ (32 * HM_WAVES)    // queries per forward workgroup
 #define HM_BK 128                // keys per ring slot / barrier
+#ifndef HM_FWD_NQ_DEFAULT
+#define HM_FWD_NQ_DEFAULT 1     // query sub-tiles per wave of the forward.  2 = the 4-wave x 64-query geometry (every K / V fragment read feeds two
+                                // MFMAs, 222 VGPRs, 2 waves / SIMD): measured 0.394 ms against 0.379 ms for 1 at the dec0 shape (round 4) -- LDS
+                                // reads are not what bounds the kernel; kept as a switch (SS_ATTN_FWD_NQ=2)
+#endif
 #ifndef HM_ABL
 #define HM_ABL 0                 // ablation mask of scripts/ubench/attn_hm_bench.hip (diagnostic builds only; 0 in the library)
 #endif
 
-template <int D> struct HMC {
+template <int D, int NW = HM_WAVES> struct HMC {
   static constexpr int CH = D / 8;                         // 16-byte chunks per row
   static constexpr int NKS = D / 16;                       // QK^T contraction steps
   static constexpr int NMT = (D + 31) / 32;                // 32-row tiles of O^T
@@ -55,7 +60,7 @@ template <int D> struct HMC {
   static constexpr int BUF = (KIMG + NCB * VPL + 255) & ~255;
   static constexpr int PADPL = PADCOL ? VPL : 0;           // shared ones plane, based at 128 mod 256
   static constexpr int LDS = 3 * BUF + (PADCOL ? 128 + PADPL : 0);
-  static constexpr int NPW = D / 16;                       // DMA pieces per wave and tile (8 waves, 128 keys)
+  static constexpr int NPW = (D / 2) / NW;                 // DMA pieces per wave and tile (D / 2 pieces of 1 KiB per 128-key tile)
   static constexpr int NKP = CH * (HM_BK / 64);            // K pieces of a tile
 };
 
@@ -98,10 +103,10 @@ __device__ __forceinline__ unsigned int hm_hi_lo(float x) {     // x ~= hi + lo,
 // piece pi = wave * NPW + j; pi < NKP: chunk plane pi / 2, key half pi % 2 (lane l <-> key 64 half + l); else column-block plane
 // (pi - NKP) / 4, key quarter (pi - NKP) % 4 (lane l <-> key 32 quarter + l / 2, 16-byte half l & 1).  Everything here is
 // wave-uniform (SGPRs): isv 0 = row operand, 1 = tr operand; rbase first key; cbase byte column; lds offset inside a ring slot.
-template <int D> struct HMPlan { int isv[HMC<D>::NPW], rbase[HMC<D>::NPW], cbase[HMC<D>::NPW]; unsigned lds[HMC<D>::NPW]; };
-template <int D>
-__device__ __forceinline__ void hm_plan(int wave_u, HMPlan<D>& P) {
-  using A = HMC<D>;
+template <int D, int NW = HM_WAVES> struct HMPlan { int isv[HMC<D, NW>::NPW], rbase[HMC<D, NW>::NPW], cbase[HMC<D, NW>::NPW]; unsigned lds[HMC<D, NW>::NPW]; };
+template <int D, int NW>
+__device__ __forceinline__ void hm_plan(int wave_u, HMPlan<D, NW>& P) {
+  using A = HMC<D, NW>;
 #pragma unroll
   for (int j = 0; j < A::NPW; ++j) {
     const int pi = wave_u * A::NPW + j;
@@ -115,20 +120,23 @@ __device__ __forceinline__ void hm_plan(int wave_u, HMPlan<D>& P) {
 }
 
 // =====================================================================================
-// forward
+// forward.  NW waves per workgroup, NQ 32-query sub-tiles per wave (round 4: <4, 2> = every K / V fragment read from LDS feeds
+// TWO MFMAs and the exponentials of one sub-tile sit between the MFMAs of the other inside ONE instruction stream; <8, 1> = the
+// round-3 geometry).  Both cover 256 queries per workgroup and stage the same 128-key ring slots.
 // =====================================================================================
-template <int D>
-__global__ void __launch_bounds__(HM_THREADS, (D <= 48 ? 4 : 2))
+template <int D, int NW, int NQ>
+__global__ void __launch_bounds__(64 * NW, (NQ == 1 ? (D <= 48 ? 4 : 2) : 2))
 k_attn_hm_fwd(const unsigned short* __restrict__ hm, int64_t NP, const int32_t* __restrict__ sidx,
               const int32_t* __restrict__ win_start, unsigned short* __restrict__ out, float* __restrict__ nlse2, int C, int H,
               float scale, int qchunks) {
-  using A = HMC<D>;
+  using A = HMC<D, NW>;
+  constexpr int THREADS = 64 * NW, BQ = 32 * NW * NQ;
   __shared__ __attribute__((aligned(256))) char smem[A::LDS];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, hh = lane >> 5;
   const int lid = hm_xcd(blockIdx.x, gridDim.x);
   const int qc = lid % qchunks; const int t_ = lid / qchunks; const int h = t_ % H; const int w = t_ / H;
   const int p0 = win_start[w], L = win_start[w + 1] - p0;
-  const int q0 = qc * HM_BQ;
+  const int q0 = qc * BQ;
   if (q0 >= L) return;
   const int64_t sec = (int64_t)H * NP * D;                          // elements per q / k / v section
   const unsigned short* const qbase = hm + ((int64_t)h * NP + p0) * D;
@@ -140,8 +148,8 @@ k_attn_hm_fwd(const unsigned short* __restrict__ hm, int64_t NP, const int32_t* 
   char* const padpl = smem + 3 * A::BUF + 128;
 
   // ---- DMA plan ----
-  HMPlan<D> P;
-  hm_plan<D>(__builtin_amdgcn_readfirstlane(wave), P);
+  HMPlan<D, NW> P;
+  hm_plan<D, NW>(__builtin_amdgcn_readfirstlane(wave), P);
   const char* const kb_u = hm_uniform_ptr(kbase);
   const char* const vb_u = hm_uniform_ptr(vbase);
   auto issue_tile = [&](int t, unsigned slot_bytes) {
@@ -158,32 +166,39 @@ k_attn_hm_fwd(const unsigned short* __restrict__ hm, int64_t NP, const int32_t* 
 
   // ---- ones plane (column D = 1.0: row D of O^T = sum_k P); written once, the DMA never touches it ----
   if (A::PADCOL) {
-    for (int e = tid; e < HM_BK * 2; e += HM_THREADS)
+    for (int e = tid; e < HM_BK * 2; e += THREADS)
       *reinterpret_cast<uint4*>(padpl + e * 16) = make_uint4((e & 1) ? 0u : 0x3F80u, 0, 0, 0);
   }
-  // ---- Q fragments (B operand of S^T = K Q^T): lane (query lr, half hh) holds Q[q][16 ks + 8 hh .. +7] ----
-  const int qslot = q0 + wave * 32 + lr;
-  hbf8_t qf[A::NKS];
-  {
-    const unsigned short* qp = qbase + (int64_t)min(qslot, L - 1) * D + 8 * hh;
+  // ---- Q fragments (B operand of S^T = K Q^T): lane (query lr, half hh) of sub-tile u holds Q[q][16 ks + 8 hh .. +7] ----
+  int qslot[NQ];
+  int32_t srow[NQ];
+  hbf8_t qf[NQ][A::NKS];
 #pragma unroll
-    for (int ks = 0; ks < A::NKS; ++ks) qf[ks] = hm_bf8(*reinterpret_cast<const uint4*>(qp + 16 * ks));
+  for (int u = 0; u < NQ; ++u) {
+    qslot[u] = q0 + (wave * NQ + u) * 32 + lr;
+    const unsigned short* qp = qbase + (int64_t)min(qslot[u], L - 1) * D + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < A::NKS; ++ks) qf[u][ks] = hm_bf8(*reinterpret_cast<const uint4*>(qp + 16 * ks));
+    srow[u] = qslot[u] < L ? sidx[p0 + qslot[u]] : -1;
   }
-  int32_t srow = qslot < L ? sidx[p0 + qslot] : -1;
 
-  f32x16_t o[A::NMT];
+  f32x16_t o[NQ][A::NMT];
   // running shift m2 (exp2 units; section 0 of hm holds q * scale * log2(e), written by the projection's epilogue in fp32
   // before the bf16 rounding) and MNEG = sixteen registers of -m2: the C operand of the first QK^T MFMA of every block, so
   // the scores leave the matrix pipe already shifted and the softmax is exp2 + pack alone (no fma per score)
-  float m2 = 0.f, lsum = 0.f;
-  f32x16_t mneg;
+  float m2[NQ], lsum[NQ];
+  f32x16_t mneg[NQ];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) mneg[r] = 0.f;
+  for (int u = 0; u < NQ; ++u) {
+    m2[u] = 0.f; lsum[u] = 0.f;
 #pragma unroll
-  for (int mt = 0; mt < A::NMT; ++mt)
+    for (int r = 0; r < 16; ++r) mneg[u][r] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
-  asm volatile("" : "+v"(mneg));
+    for (int mt = 0; mt < A::NMT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[u][mt][r] = 0.f;
+    asm volatile("" : "+v"(mneg[u]));
+  }
 
   // per-lane read bases (inside a ring slot): K chunk plane hh (+ 2 ks), row lr; V: 16-lane group (hh, lr >> 4) reads rows
   // 4 hh + q (+8), columns 4 p .. of column block 2 mt + (lr >> 4)
@@ -202,68 +217,84 @@ k_attn_hm_fwd(const unsigned short* __restrict__ hm, int64_t NP, const int32_t* 
   typedef const __attribute__((address_space(3))) hu32x4_t lds_u4_t;
 
   // ---- one 32-key block = rows IMM .. IMM + 31 of the ring slot whose per-lane bases are kb / vb[], in three pieces so that
-  // the tile loop can issue QK^T of block b+1 BEFORE the exponentials of block b (matrix and vector work of one wave overlap)
-  auto qk_block = [&](f32x16_t& s, const unsigned kb, const int IMM) {
+  // the tile loop can issue QK^T of block b+1 BEFORE the exponentials of block b (matrix and vector work of one wave overlap);
+  // a K / V fragment is read ONCE and multiplied with the operands of all NQ sub-tiles
+  auto qk_block = [&](f32x16_t (&s)[NQ], const unsigned kb, const int IMM) {
 #pragma unroll
     for (int ks = 0; ks < A::NKS; ++ks) {
       hbf8_t a = __builtin_bit_cast(hbf8_t, *(lds_u4_t*)(kb + ks * 2 * A::KPL + IMM * 16));
-      if (!(HM_ABL & 32)) s = (ks == 0) ? HM_MFMA32(a, qf[ks], mneg) : HM_MFMA32(a, qf[ks], s);
-      else if (ks == 0) s = mneg;
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        if (!(HM_ABL & 32)) s[u] = (ks == 0) ? HM_MFMA32(a, qf[u][ks], mneg[u]) : HM_MFMA32(a, qf[u][ks], s[u]);
+        else if (ks == 0) s[u] = mneg[u];
+      }
     }
   };
   // tail mask, block maximum, (rare) move of the running shift
-  auto max_block = [&](f32x16_t& s, const int kv0, const bool first) {
-    if (kv0 + 32 > L) {               // keys past the window end (last tile only; wave-uniform branch)
-      asm volatile("; tail: mask keys past the window end" ::: "memory");
+  auto max_block = [&](f32x16_t (&sv)[NQ], const int kv0, const bool first) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (kv0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[r] = -INFINITY;
-    }
-    if (HM_ABL & 8) return;
-    float mx = hm_max3(s[0], s[1], s[2]);
+    for (int u = 0; u < NQ; ++u) {
+      f32x16_t& s = sv[u];
+      if (kv0 + 32 > L) {               // keys past the window end (last tile only; wave-uniform branch)
+        asm volatile("; tail: mask keys past the window end" ::: "memory");
 #pragma unroll
-    for (int r = 3; r < 15; r += 2) mx = hm_max3(mx, s[r], s[r + 1]);
-    mx = fmaxf(mx, s[15]);
-    {   // maximum over the two half-waves: after the swap one of (a, b) is this lane's value, the other its partner's
-      unsigned int u = __float_as_uint(mx);
-      auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-      mx = hm_max3(mx, __uint_as_float(r[0]), __uint_as_float(r[1]));
-    }
-    const float thr = first ? -INFINITY : HM_THR;
-    if (__any(mx > thr)) {        // the shift moves only past the threshold; everything so far is rescaled exactly once
-      const float dlt = mx > thr ? mx : 0.f;
-      const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-dlt);
-      m2 += dlt;
-      lsum *= alpha;
+        for (int r = 0; r < 16; ++r)
+          if (kv0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= L) s[r] = -INFINITY;
+      }
+      if (HM_ABL & 8) continue;
+      float mx = hm_max3(s[0], s[1], s[2]);
 #pragma unroll
-      for (int mt = 0; mt < A::NMT; ++mt)
+      for (int r = 3; r < 15; r += 2) mx = hm_max3(mx, s[r], s[r + 1]);
+      mx = fmaxf(mx, s[15]);
+      {   // maximum over the two half-waves: after the swap one of (a, b) is this lane's value, the other its partner's
+        unsigned int uu = __float_as_uint(mx);
+        auto r = __builtin_amdgcn_permlane32_swap(uu, uu, false, false);
+        mx = hm_max3(mx, __uint_as_float(r[0]), __uint_as_float(r[1]));
+      }
+      const float thr = first ? -INFINITY : HM_THR;
+      if (__any(mx > thr)) {        // the shift moves only past the threshold; everything so far is rescaled exactly once
+        const float dlt = mx > thr ? mx : 0.f;
+        const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-dlt);
+        m2[u] += dlt;
+        lsum[u] *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+        for (int mt = 0; mt < A::NMT; ++mt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] -= dlt; mneg[r] = -m2; }
-      asm volatile("" : "+v"(mneg));
+          for (int r = 0; r < 16; ++r) o[u][mt][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] -= dlt; mneg[u][r] = -m2[u]; }
+        asm volatile("" : "+v"(mneg[u]));
+      }
     }
   };
-  auto pv_block = [&](f32x16_t& s, const unsigned (&vb)[A::NMT], const int IMM) {
+  auto pv_block = [&](f32x16_t (&sv)[NQ], const unsigned (&vb)[A::NMT], const int IMM) {
+    hbf8_t pf[NQ][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (HM_ABL & 4) s[r] = s[r] * 0.001f;
-      else s[r] = __builtin_amdgcn_exp2f(s[r]);
-    }
-    if (!A::PADCOL) {
+    for (int u = 0; u < NQ; ++u) {
+      f32x16_t& s = sv[u];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) lsum += s[r];
-    }
-    hbf8_t pf[2];
+      for (int r = 0; r < 16; ++r) {
+        if (HM_ABL & 4) s[r] = s[r] * 0.001f;
+        else s[r] = __builtin_amdgcn_exp2f(s[r]);
+      }
+      if (!A::PADCOL) {
 #pragma unroll
-    for (int ss = 0; ss < 2; ++ss) {
-      uint4 pk;
-      pk.x = pack_bf16x2(s[8 * ss + 0], s[8 * ss + 1]); pk.y = pack_bf16x2(s[8 * ss + 2], s[8 * ss + 3]);
-      pk.z = pack_bf16x2(s[8 * ss + 4], s[8 * ss + 5]); pk.w = pack_bf16x2(s[8 * ss + 6], s[8 * ss + 7]);
-      pf[ss] = hm_bf8(pk);
+        for (int r = 0; r < 16; ++r) lsum[u] += s[r];
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        uint4 pk;
+        pk.x = pack_bf16x2(s[8 * ss + 0], s[8 * ss + 1]); pk.y = pack_bf16x2(s[8 * ss + 2], s[8 * ss + 3]);
+        pk.z = pack_bf16x2(s[8 * ss + 4], s[8 * ss + 5]); pk.w = pack_bf16x2(s[8 * ss + 6], s[8 * ss + 7]);
+        pf[u][ss] = hm_bf8(pk);
+      }
     }
     // O^T += V^T P^T; element j of lane half hh in step ss <-> key 16 ss + 8 (j>>2) + 4 hh + (j&3) of the block
-    if (HM_ABL & 16) { asm volatile("" :: "v"(pf[0]), "v"(pf[1])); return; }
+    if (HM_ABL & 16) {
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) asm volatile("" :: "v"(pf[u][0]), "v"(pf[u][1]));
+      return;
+    }
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
 #pragma unroll
@@ -271,16 +302,20 @@ k_attn_hm_fwd(const unsigned short* __restrict__ hm, int64_t NP, const int32_t* 
         const unsigned va = vb[mt] + (IMM + 16 * ss) * 32;
         hbf8_t vf = hm_cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((hlds_s4_t*)(va)),
                            __builtin_amdgcn_ds_read_tr16_b64_v4i16((hlds_s4_t*)(va + 8 * 32)));
-        o[mt] = HM_MFMA32(vf, pf[ss], o[mt]);
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) o[u][mt] = HM_MFMA32(vf, pf[u][ss], o[u][mt]);
       }
     }
   };
 
   // every compiler-visible load retires HERE: inside the loop the vector-memory counter belongs to the DMA pieces alone (a
   // pending ordinary load would make hipcc drain vmcnt(0) at its first use inside the loop, every iteration)
-  asm volatile("" : "+v"(srow));
 #pragma unroll
-  for (int ks = 0; ks < A::NKS; ++ks) asm volatile("" : "+v"(qf[ks]));
+  for (int u = 0; u < NQ; ++u) {
+    asm volatile("" : "+v"(srow[u]));
+#pragma unroll
+    for (int ks = 0; ks < A::NKS; ++ks) asm volatile("" : "+v"(qf[u][ks]));
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ones plane is written before the first barrier releases its readers
   unsigned slot_off = 0;                                   // byte offset of tile t's ring slot
   for (int t = 0; t < ntiles; ++t) {
@@ -289,7 +324,9 @@ k_attn_hm_fwd(const unsigned short* __restrict__ hm, int64_t NP, const int32_t* 
     if (A::NPW == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else if (A::NPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if (A::NPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (A::NPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (A::NPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     if (!(HM_ABL & 2)) { __builtin_amdgcn_s_barrier(); }
     __builtin_amdgcn_sched_barrier(0);
     issue_tile(t + 2, slot_off == 0 ? 2u * A::BUF : slot_off - A::BUF);
@@ -301,7 +338,7 @@ k_attn_hm_fwd(const unsigned short* __restrict__ hm, int64_t NP, const int32_t* 
     for (int mt = 0; mt < A::NMT; ++mt) asm volatile("" : "+v"(vb[mt]));
     const int kv0 = t * HM_BK;
     // blocks past the window end (last tile of a short window) run on the clamped rows with every score masked: P = 0
-    f32x16_t sa, sb;
+    f32x16_t sa[NQ], sb[NQ];
     qk_block(sa, kb, 0);
     max_block(sa, kv0, t == 0);
     qk_block(sb, kb, 32);
@@ -319,39 +356,51 @@ k_attn_hm_fwd(const unsigned short* __restrict__ hm, int64_t NP, const int32_t* 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-staged pieces of the last two issues (LDS must outlive them)
 
   // ---- epilogue: row sums, lse, normalised output rows ----
-  float lt;
-  if (A::PADCOL) {
-    constexpr int LR = D % 32, REG = (LR >> 3) * 4 + (LR & 3), HF = (LR >> 2) & 1;
-    float mine = o[D / 32][REG], other = hm_swap32(mine);
-    lt = (hh == HF) ? mine : other;
-  } else {
-    lt = lsum + hm_swap32(lsum);
-  }
-  if (qslot < L) {
-    // -lse in exp2 units: the backward kernels start their score accumulators from it (C operand of the first MFMA)
-    if (hh == 0) nlse2[(int64_t)h * NP + p0 + qslot] = -(m2 + __log2f(lt));
-    if (srow >= 0 && !(HM_ABL & 64)) {
-      const float inv = 1.f / lt;
-      unsigned short* op = out + (int64_t)srow * C + h * D + 8 * hh;
-      constexpr int NG = D / 8;
 #pragma unroll
-      for (int j = 0; j < (NG + 1) / 2; ++j) {
-        const int ga = 2 * j, gb = 2 * j + 1;
-        uint2 a, b;
-        a.x = pack_bf16x2(o[ga >> 2][4 * (ga & 3) + 0] * inv, o[ga >> 2][4 * (ga & 3) + 1] * inv);
-        a.y = pack_bf16x2(o[ga >> 2][4 * (ga & 3) + 2] * inv, o[ga >> 2][4 * (ga & 3) + 3] * inv);
-        if (gb < NG) {
-          b.x = pack_bf16x2(o[gb >> 2][4 * (gb & 3) + 0] * inv, o[gb >> 2][4 * (gb & 3) + 1] * inv);
-          b.y = pack_bf16x2(o[gb >> 2][4 * (gb & 3) + 2] * inv, o[gb >> 2][4 * (gb & 3) + 3] * inv);
-          auto rx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
-          auto ry = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
-          *reinterpret_cast<uint4*>(op + 16 * j) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
-        } else {
-          *reinterpret_cast<uint2*>(out + (int64_t)srow * C + h * D + 8 * ga + 4 * hh) = a;
+  for (int u = 0; u < NQ; ++u) {
+    float lt;
+    if (A::PADCOL) {
+      constexpr int LR = D % 32, REG = (LR >> 3) * 4 + (LR & 3), HF = (LR >> 2) & 1;
+      float mine = o[u][D / 32][REG], other = hm_swap32(mine);
+      lt = (hh == HF) ? mine : other;
+    } else {
+      lt = lsum[u] + hm_swap32(lsum[u]);
+    }
+    if (qslot[u] < L) {
+      // -lse in exp2 units: the backward kernels start their score accumulators from it (C operand of the first MFMA).  A BORROWED
+      // slot (duplicate padding, sidx < 0) publishes -inf: its recomputed probabilities are exactly 0 in the backward, so the
+      // dK / dV kernel may stream any finite dO row for it (round 4: dO is read in place, no head-major copy)
+      if (hh == 0) nlse2[(int64_t)h * NP + p0 + qslot[u]] = srow[u] >= 0 ? -(m2[u] + __log2f(lt)) : -INFINITY;
+      if (srow[u] >= 0 && !(HM_ABL & 64)) {
+        const float inv = 1.f / lt;
+        unsigned short* op = out + (int64_t)srow[u] * C + h * D + 8 * hh;
+        constexpr int NG = D / 8;
+#pragma unroll
+        for (int j = 0; j < (NG + 1) / 2; ++j) {
+          const int ga = 2 * j, gb = 2 * j + 1;
+          uint2 a, b;
+          a.x = pack_bf16x2(o[u][ga >> 2][4 * (ga & 3) + 0] * inv, o[u][ga >> 2][4 * (ga & 3) + 1] * inv);
+          a.y = pack_bf16x2(o[u][ga >> 2][4 * (ga & 3) + 2] * inv, o[u][ga >> 2][4 * (ga & 3) + 3] * inv);
+          if (gb < NG) {
+            b.x = pack_bf16x2(o[u][gb >> 2][4 * (gb & 3) + 0] * inv, o[u][gb >> 2][4 * (gb & 3) + 1] * inv);
+            b.y = pack_bf16x2(o[u][gb >> 2][4 * (gb & 3) + 2] * inv, o[u][gb >> 2][4 * (gb & 3) + 3] * inv);
+            auto rx = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+            auto ry = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+            *reinterpret_cast<uint4*>(op + 16 * j) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+          } else {
+            *reinterpret_cast<uint2*>(out + (int64_t)srow[u] * C + h * D + 8 * ga + 4 * hh) = a;
+          }
         }
       }
     }
   }
+}
+
+// geometry of the forward: 8 waves x 32 queries (default) or, SS_ATTN_FWD_NQ=2, 4 waves x 64 queries
+static int hm_fwd_nq() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SS_ATTN_FWD_NQ"); v = e ? (atoi(e) == 2 ? 2 : 1) : HM_FWD_NQ_DEFAULT; }
+  return v;
 }
 
 int ss_attn_hm_fwd(const void* hm, int64_t np, const int32_t* sidx, const int32_t* win_start, int W, int max_window,
@@ -359,13 +408,25 @@ int ss_attn_hm_fwd(const void* hm, int64_t np, const int32_t* sidx, const int32_
   const int D = C / H;
   if ((C & 7) || max_window <= 0 || W <= 0) return SS_ERR_ARG;
   const int qchunks = (max_window + HM_BQ - 1) / HM_BQ;
-  dim3 g((unsigned)(W * H * qchunks)), b(HM_THREADS);
   const unsigned short* q = (const unsigned short*)hm; unsigned short* o = (unsigned short*)out;
+  dim3 g((unsigned)(W * H * qchunks));
+  if (hm_fwd_nq() == 2) {
+    dim3 b(256);
+    switch (D) {
+      case 16: SS_LAUNCH((k_attn_hm_fwd<16, 4, 2>), g, b, 0, st, q, np, sidx, win_start, o, nlse2, C, H, scale, qchunks); break;
+      case 32: SS_LAUNCH((k_attn_hm_fwd<32, 4, 2>), g, b, 0, st, q, np, sidx, win_start, o, nlse2, C, H, scale, qchunks); break;
+      case 48: SS_LAUNCH((k_attn_hm_fwd<48, 4, 2>), g, b, 0, st, q, np, sidx, win_start, o, nlse2, C, H, scale, qchunks); break;
+      case 64: SS_LAUNCH((k_attn_hm_fwd<64, 4, 2>), g, b, 0, st, q, np, sidx, win_start, o, nlse2, C, H, scale, qchunks); break;
+      default: return SS_ERR_ARG;
+    }
+    return SS_OK;
+  }
+  dim3 b(HM_THREADS);
   switch (D) {
-    case 16: SS_LAUNCH((k_attn_hm_fwd<16>), g, b, 0, st, q, np, sidx, win_start, o, nlse2, C, H, scale, qchunks); break;
-    case 32: SS_LAUNCH((k_attn_hm_fwd<32>), g, b, 0, st, q, np, sidx, win_start, o, nlse2, C, H, scale, qchunks); break;
-    case 48: SS_LAUNCH((k_attn_hm_fwd<48>), g, b, 0, st, q, np, sidx, win_start, o, nlse2, C, H, scale, qchunks); break;
-    case 64: SS_LAUNCH((k_attn_hm_fwd<64>), g, b, 0, st, q, np, sidx, win_start, o, nlse2, C, H, scale, qchunks); break;
+    case 16: SS_LAUNCH((k_attn_hm_fwd<16, 8, 1>), g, b, 0, st, q, np, sidx, win_start, o, nlse2, C, H, scale, qchunks); break;
+    case 32: SS_LAUNCH((k_attn_hm_fwd<32, 8, 1>), g, b, 0, st, q, np, sidx, win_start, o, nlse2, C, H, scale, qchunks); break;
+    case 48: SS_LAUNCH((k_attn_hm_fwd<48, 8, 1>), g, b, 0, st, q, np, sidx, win_start, o, nlse2, C, H, scale, qchunks); break;
+    case 64: SS_LAUNCH((k_attn_hm_fwd<64, 8, 1>), g, b, 0, st, q, np, sidx, win_start, o, nlse2, C, H, scale, qchunks); break;
     default: return SS_ERR_ARG;
   }
   return SS_OK;
@@ -461,7 +522,7 @@ k_attn_hm_dq(const unsigned short* __restrict__ hm, int64_t NP, const unsigned s
         dsum += __uint_as_float(ug[j] << 16) * __uint_as_float(uo[j] << 16);
         dsum += __uint_as_float(ug[j] & 0xffff0000u) * __uint_as_float(uo[j] & 0xffff0000u);
       }
-      if (qok) *reinterpret_cast<uint4*>(doh + (hrow + qslot) * D + 16 * ks + 8 * hh) = g;    // head-major copy for dK/dV
+      if (qok && doh) *reinterpret_cast<uint4*>(doh + (hrow + qslot) * D + 16 * ks + 8 * hh) = g;    // head-major copy for dK/dV (round-3 path)
     }
   }
   float ndl = -(dsum + hm_swap32(dsum));
@@ -609,7 +670,12 @@ __device__ __forceinline__ void hm_glds4s(const void* sbase, unsigned voff, unsi
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0" ::"s"(sbase), "v"(voff), "s"(lds_wave_base) : "memory");
 }
 
-template <int D>
+#define HMK_MAXW 1024                // longest window whose row map fits the in-place path's LDS table
+
+// INPLACE (round 4): dO is streamed straight from the (n, C) gradient tensor -- the DMA's per-lane source offset is
+// sidx[slot] * 2 C + h * 2 D + chunk, the window's row map sits in LDS -- instead of from a head-major copy the dQ kernel had to
+// write (157 MB written + 157 MB read per dec0 launch).  Borrowed slots stream row 0: their -lse2 is -inf (forward), so P = 0.
+template <int D, bool INPLACE>
 __global__ void __launch_bounds__(HMK_THREADS, 2)
 k_attn_hm_dkv(const unsigned short* __restrict__ hm, int64_t NP, const unsigned short* __restrict__ doh,
               const float* __restrict__ nlse2, const float* __restrict__ ndelta, const int32_t* __restrict__ sidx,
@@ -619,7 +685,7 @@ k_attn_hm_dkv(const unsigned short* __restrict__ hm, int64_t NP, const unsigned 
   constexpr int NPW = D / 16;                               // 16-byte DMA pieces per wave and tile (+ 1 dword piece)
   constexpr int OFF_L = 2 * A::IMG, OFF_D = OFF_L + 256, OFF_X = OFF_D + 256;   // -lse2[64], -delta[64], dummy target
   constexpr int BUF = OFF_X + 512;
-  __shared__ __attribute__((aligned(256))) char smem[3 * BUF];
+  __shared__ __attribute__((aligned(256))) char smem[3 * BUF + (INPLACE ? HMK_MAXW * 4 : 0)];
   typedef __attribute__((ext_vector_type(4))) unsigned int hu32x4_t;
   typedef const __attribute__((address_space(3))) hu32x4_t lds_u4_t;
   typedef __attribute__((ext_vector_type(4))) float hf32x4_t;
@@ -633,28 +699,47 @@ k_attn_hm_dkv(const unsigned short* __restrict__ hm, int64_t NP, const unsigned 
   const int64_t sec = (int64_t)H * NP * D;
   const int64_t hrow = (int64_t)h * NP + p0;
   const char* const qb_u = hm_uniform_ptr(hm + hrow * D);
-  const char* const gb_u = hm_uniform_ptr(doh + hrow * D);
+  const char* const gb_u = hm_uniform_ptr(INPLACE ? doh + h * D : doh + hrow * D);       // INPLACE: doh = the (n, C) dO tensor
   const char* const lb_u = hm_uniform_ptr(nlse2 + hrow);
   const char* const db_u = hm_uniform_ptr(ndelta + hrow);
   const int ntiles = (L + HMK_BQ - 1) / HMK_BQ;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  auto issue_tile = [&](int t, unsigned slot_bytes) {
+  int32_t* const srow_s = reinterpret_cast<int32_t*>(smem + 3 * BUF);
+  // tile t, ring slot at slot_bytes; grow = the (n, C) row of this lane's query slot (INPLACE; borrowed slots: row 0)
+  auto issue_tile = [&](int t, unsigned slot_bytes, int grow) {
     const int q0 = min(t, ntiles - 1) * HMK_BQ;
     const int row = min(q0 + lane, L - 1);
+    const unsigned goff = INPLACE ? (unsigned)grow * (2u * (unsigned)C) : 0u;
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
       const int pi = wave_u * NPW + j;
       const int isg = pi >= A::CH, c = isg ? pi - A::CH : pi;
-      const unsigned off = __umul24((unsigned)row, 2u * D) + c * 16;
+      const unsigned off = (INPLACE && isg) ? goff + c * 16 : __umul24((unsigned)row, 2u * D) + c * 16;
       hm_glds16s(isg ? gb_u : qb_u, off, lds0 + slot_bytes + isg * A::IMG + A::plane(c));
     }
     // waves 0 / 1: -lse2 / -delta of the 64 queries; waves 2 / 3 repeat them into a dummy target (uniform vmcnt)
     hm_glds4s((wave_u & 1) ? db_u : lb_u, (unsigned)row * 4u,
               lds0 + slot_bytes + (wave_u >= 2 ? OFF_X + (wave_u & 1) * 256 : ((wave_u & 1) ? OFF_D : OFF_L)));
   };
-  issue_tile(0, 0u);
-  issue_tile(1, (unsigned)BUF);
+  if (INPLACE) {
+    // The window's row map goes to LDS for tiles 2 ..; tiles 0 and 1 take their rows straight from registers, so the first DMA
+    // pieces wait for ONE global round trip of a 4-byte load instead of a staging pass + workgroup barrier (the q~ pieces -- waves
+    // 0 / 1 -- do not wait at all: the row map only addresses dO).  The loop's first barrier publishes the table.
+    constexpr int NST = HMK_MAXW / HMK_THREADS;
+    int32_t st[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) { const int e = tid + i * HMK_THREADS; st[i] = e < L ? sidx[p0 + e] : 0; }
+    const int g0 = max(sidx[p0 + min(lane, L - 1)], 0);
+    const int g1 = max(sidx[p0 + min(min(1, ntiles - 1) * HMK_BQ + lane, L - 1)], 0);
+    issue_tile(0, 0u, g0);
+    issue_tile(1, (unsigned)BUF, g1);
+#pragma unroll
+    for (int i = 0; i < NST; ++i) { const int e = tid + i * HMK_THREADS; if (e < L) srow_s[e] = max(st[i], 0); }
+  } else {
+    issue_tile(0, 0u, 0);
+    issue_tile(1, (unsigned)BUF, 0);
+  }
 
   // ---- this lane's key: K and V fragments (B operands): lane (key lr, half hh) holds K[key][16 ks + 8 hh .. +7] ----
   const int kslot = k0 + wave * 32 + lr;
@@ -737,6 +822,7 @@ k_attn_hm_dkv(const unsigned short* __restrict__ hm, int64_t NP, const unsigned 
       }
   };
 
+  if (INPLACE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the row map is written before the first barrier releases its readers
   unsigned slot_off = 0;
   for (int t = 0; t < ntiles; ++t) {
     if (NPW == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -745,7 +831,7 @@ k_attn_hm_dkv(const unsigned short* __restrict__ hm, int64_t NP, const unsigned 
     else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    issue_tile(t + 2, slot_off == 0 ? 2u * BUF : slot_off - BUF);
+    issue_tile(t + 2, slot_off == 0 ? 2u * BUF : slot_off - BUF, INPLACE ? srow_s[min(min(t + 2, ntiles - 1) * HMK_BQ + lane, L - 1)] : 0);
     unsigned rb = roff + slot_off, cb_ = coff + slot_off, tb[A::NMT];
 #pragma unroll
     for (int mt = 0; mt < A::NMT; ++mt) tb[mt] = toff[mt] + slot_off;
@@ -793,20 +879,32 @@ k_attn_hm_dkv(const unsigned short* __restrict__ hm, int64_t NP, const unsigned 
   }
 }
 
+// inplace != 0: `doh` is the (n, C) dO tensor itself (see k_attn_hm_dkv)
 int ss_attn_hm_dkv(const void* hm, int64_t np, const void* doh, const float* nlse2, const float* ndelta, const int32_t* sidx,
-                   const int32_t* win_start, int W, int max_window, void* dqkv, void* extra, int C, int H, hipStream_t st) {
+                   const int32_t* win_start, int W, int max_window, void* dqkv, void* extra, int C, int H, int inplace, hipStream_t st) {
   const int D = C / H;
-  if ((C & 7) || max_window <= 0 || W <= 0) return SS_ERR_ARG;
+  if ((C & 7) || max_window <= 0 || W <= 0 || (inplace && max_window > HMK_MAXW)) return SS_ERR_ARG;
   const int kchunks = (max_window + HMK_BKEYS - 1) / HMK_BKEYS;
   dim3 g((unsigned)(W * H * kchunks)), b(HMK_THREADS);
   const unsigned short* q = (const unsigned short*)hm;
-#define SS_HK_CASE(DD) case DD: SS_LAUNCH((k_attn_hm_dkv<DD>), g, b, 0, st, q, np, (const unsigned short*)doh, nlse2, ndelta, sidx, win_start, (unsigned short*)dqkv, (unsigned short*)extra, C, H, kchunks); break;
+#define SS_HK_CASE(DD) case DD: if (inplace) SS_LAUNCH((k_attn_hm_dkv<DD, true>), g, b, 0, st, q, np, (const unsigned short*)doh, nlse2, ndelta, sidx, win_start, (unsigned short*)dqkv, (unsigned short*)extra, C, H, kchunks); \
+  else SS_LAUNCH((k_attn_hm_dkv<DD, false>), g, b, 0, st, q, np, (const unsigned short*)doh, nlse2, ndelta, sidx, win_start, (unsigned short*)dqkv, (unsigned short*)extra, C, H, kchunks); break;
   switch (D) {
     SS_HK_CASE(16) SS_HK_CASE(32) SS_HK_CASE(48) SS_HK_CASE(64)
     default: return SS_ERR_ARG;
   }
 #undef SS_HK_CASE
   return SS_OK;
+}
+
+// dO in place is possible while the window's row map fits the LDS table and a row offset fits the DMA's 32-bit lane offset
+static int hm_do_inplace(int64_t n, int channels, int max_window) {
+  static int env = -1;
+  // default OFF (measured, round 4, dec0 shape, one box, interleaved): the head-major copy costs 314 MB of traffic per launch pair
+  // but its contiguous 1-KiB DMA pieces stream faster than 16-byte pieces of 64 scattered 1,536-byte rows -- dQ 0.641 -> 0.617 ms,
+  // dK/dV 0.720 -> 0.766 ms, the pair 1.361 -> 1.384 ms.  SS_ATTN_DO_INPLACE=1 selects the in-place path (less traffic, 1.7 % slower).
+  if (env < 0) { const char* e = getenv("SS_ATTN_DO_INPLACE"); env = (e && atoi(e) == 1) ? 1 : 0; }
+  return env && max_window <= HMK_MAXW && (uint64_t)n * (uint64_t)channels * 2ull < (1ull << 32);
 }
 
 // =====================================================================================
@@ -877,11 +975,12 @@ extern "C" int ss_window_attn_hm_bwd(const void* hm, const void* out, const void
   float* ndelta = (float*)workspace;
   char* doh = (char*)workspace + hm_al256((size_t)n_pad * num_heads * 4);
   char* extra = doh + hm_al256((size_t)n_pad * channels * 2);
-  int rc = ss_attn_hm_dq(hm, n_pad, dout, out, neg_lse2, ndelta, doh, sidx, win_start, num_windows, max_window, dqkv, channels,
-                         num_heads, scale, stream);
+  const int inplace = hm_do_inplace(n, channels, max_window);
+  int rc = ss_attn_hm_dq(hm, n_pad, dout, out, neg_lse2, ndelta, inplace ? nullptr : doh, sidx, win_start, num_windows, max_window, dqkv,
+                         channels, num_heads, scale, stream);
   if (rc) return rc;
-  rc = ss_attn_hm_dkv(hm, n_pad, doh, neg_lse2, ndelta, sidx, win_start, num_windows, max_window, dqkv, extra, channels, num_heads,
-                      stream);
+  rc = ss_attn_hm_dkv(hm, n_pad, inplace ? dout : (const void*)doh, neg_lse2, ndelta, sidx, win_start, num_windows, max_window, dqkv, extra,
+                      channels, num_heads, inplace, stream);
   if (rc) return rc;
   if (n_pad > n) rc = ss_attn_fix_borrowed(gidx, sidx, n_pad, extra, dqkv, channels, SS_BF16, stream);
   return rc;

@@ -69,7 +69,11 @@ class StageGradExchange:
         self._hooks = []
         self._sequence, self._cursor = [], 0          # hook form: the fixed launch order and how far this step has got in it
         self._pending = []                            # split form: (work handle | None, buffer, needs division)
-        self._avg_ok = None           # does the backend implement ReduceOp.AVG?  (probed by the first packed reduce)
+        # ReduceOp.AVG only where the backend is known to implement it for device tensors (RCCL / NCCL); gloo accepts the enum for
+        # CUDA tensors without raising and hands back garbage (NaN: tests/test_hip_split_exchange.py), so it is never probed there
+        self._avg_ok = None
+        if dist.is_available() and dist.is_initialized():
+            self._avg_ok = True if dist.get_backend(process_group) == "nccl" else False
         self.whole = {}
         self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())     # force: one-rank rehearsal
         if not self.active:

@@ -79,15 +79,19 @@ class SteadyStateStep:
         self.eager_steps += 1
         out = {k: v.detach() for k, v in self.fn(plan, inputs).items()}
         if self.tail is not None:
-            if self.between is not None:
-                # the collective launch is host code outside the graphs: not part of what the sync check must clear (a gloo
-                # all-reduce of device tensors reads them on the host)
-                if arm is not None:
-                    arm(False)
-                self.between()
-                if arm is not None:
-                    arm(True)
-            self.tail()
+            if arm is None:
+                if self.between is not None:
+                    self.between()
+                self.tail()
+            else:
+                # the sync-checked step: fn and tail run under torch's PROCESS-wide sync detector; between() -- host code outside the
+                # graphs, typically an asynchronous collective whose backend may work on a thread of its own (gloo reads device
+                # tensors on the host there) -- is called after the detector is disarmed, i.e. AFTER tail() in this one step.
+                # (Legal for a gradient exchange: what between() reduces was packed by fn, tail() does not touch it.)
+                self.tail()
+                arm(False)
+                if self.between is not None:
+                    self.between()
         return out
 
     def __call__(self, plan, inputs, key=None):
