@@ -356,10 +356,16 @@ def secondary_lines(log, steps=3):
             del batches
             return tot, dt_, dups
 
+        # Two passes over the same size sequence.  The FIRST pass of a fresh process also loads, from disk, the hipBLASLt / rocBLAS
+        # code objects of every GEMM shape class these sizes touch (a cold box: 145 ms/step against 101 ms warm, round 4); a
+        # training run pays that once in its first few hundred steps.  `value` is the second pass -- the steady state of a run --,
+        # the first is reported beside it.  (The Mix3D line below runs the same sizes after both, i.e. warm as well.)
+        tot0, dt0, _ = eager_line(False)
         tot, dt, _ = eager_line(False)
         out["variable_size_training_b2"] = dict(metric="Gaussians/s encoder fwd+bwd, EAGER launches, 2 chunks per step of 60,000-192,000 Gaussians each (a new plan shape every step), 1 GPU",
                                                 value=tot / dt, unit="Gaussians/s", ms_per_step=dt / steps * 1e3, steps=steps,
-                                                gaussians_per_step=tot / steps, dtype="bf16")
+                                                gaussians_per_step=tot / steps, first_pass_ms_per_step=dt0 / steps * 1e3,
+                                                first_pass_value=tot0 / dt0, dtype="bf16")
         gc.collect(); torch.cuda.empty_cache()
         # ---- the Mix3D regime (round 4): the SAME batches with the two samples merged into one batch element, as point_collate_fn
         # does in 80 % of the reference's training steps -- duplicate voxels at level 0, handled inside the MFMA conv paths

@@ -3,12 +3,12 @@
 # queue, kernels ranked, and the tail of small launches.  (The plan build runs on a side stream: other queue ids.)
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
-O=gpurun_out/r3s
+O=gpurun_out/r4s
 rm -rf $O; mkdir -p $O
 SS_BENCH_CALIBRATE=0 rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python bench.py --steps 6 --warmup 2 --no-pmc --no-secondary --no-cpu-baseline > $O/run.log 2>&1
 python - <<'PY'
 import csv, glob, os, collections
-O = "gpurun_out/r3s"
+O = "gpurun_out/r4s"
 trace = max(glob.glob(O + "/tr/*/*kernel_trace.csv"), key=os.path.getsize)
 rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
 qkey = "Queue_Id" if "Queue_Id" in rows[0] else "Stream_Id"
