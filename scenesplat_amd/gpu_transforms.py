@@ -34,6 +34,64 @@ def grid_sample_train(coord, grid_size, generator=None, return_inverse=False):
     return out
 
 
+@torch.no_grad()
+def grid_sample_test(coord, grid_size, return_inverse=False):
+    """GridSample(mode="test") on the device (pointcept/datasets/transform.py:1302-1330): the fragment generator of the
+    open-vocabulary tester (engines/test.py:300-351).  A voxel with c points contributes its (i mod c)-th member to fragment i,
+    i = 0 .. max(c) - 1, so every fragment holds ONE point per occupied voxel and the fragments together cover every point.
+    -> dict(index (P, n_vox) int64: row p = the `index` of fragment p; grid_coord (n_vox, 3) int32 (the same for every fragment:
+    members of a voxel share it); count (n_vox,) [, inverse (N,)]).  Members are enumerated in row order (stable sort; the
+    reference's numpy argsort leaves the order inside a voxel unspecified)."""
+    if not coord.is_cuda:
+        raise RuntimeError("grid_sample_test: GPU tensor required (no CPU fallback)")
+    gc = torch.floor(coord / grid_size).to(torch.int64)
+    gc = gc - gc.amin(0, keepdim=True)
+    if int(gc.max()) >= (1 << 21):
+        raise ValueError("grid extent exceeds 21 bits per axis")
+    key = ((gc[:, 0] << 42) | (gc[:, 1] << 21) | gc[:, 2]).unsqueeze(0).contiguous()
+    order, _, _ = nv.argsort_i64(key, 63, want_inverse=False, want_sorted=False)
+    order = order[0]
+    cluster, idx_ptr, head, n_out = nv.pool_partition(key[0], order, 0)
+    n = int(n_out.item())
+    ptr = idx_ptr[:n + 1].long()
+    count = ptr[1:] - ptr[:-1]
+    parts = int(count.max())
+    sel = ptr[:-1].unsqueeze(0) + torch.arange(parts, device=coord.device).unsqueeze(1) % count.unsqueeze(0)       # (P, n_vox)
+    index = order.long()[sel]
+    out = dict(index=index, grid_coord=gc[index[0]].to(torch.int32), count=count)
+    if return_inverse:
+        out["inverse"] = cluster.long()
+    return out
+
+
+@torch.no_grad()
+def open_vocab_fragments(model, data_dict, text_embeddings, grid_size, chunk_size=600000, topk=None, confidence_threshold=0.1,
+                         ignore_index=-1, feat_keys=None):
+    """The fragment loop of ZeroShotSemSegTester.test (pointcept/engines/test.py:300-378) on the device: GridSample(mode="test")
+    fragments -> model(fragment, chunk_size)["point_feat"]["feat"] -> pred[index] += sigmoid(feat text^T) (fused scan +
+    accumulate, csrc/scan.hip) -> per point either the top-k classes (ScanNet++: `pred.topk(3)`, test.py:371-374) or
+    arg-max with the confidence threshold (test.py:376-378).  data_dict: coord (N, 3), feat (N, C) (or the `feat_keys` columns to
+    concatenate, as Collect does), all on the GPU.  -> (pred_labels (N,) | (N, k) int64, pred (N, classes) f32)."""
+    coord = data_dict["coord"]
+    feat = data_dict["feat"] if feat_keys is None else torch.cat([data_dict[k].float() for k in feat_keys], 1)
+    frag = grid_sample_test(coord, grid_size)
+    text = text_embeddings.to(torch.bfloat16).contiguous()
+    pred = torch.zeros((coord.shape[0], text.shape[0]), dtype=torch.float32, device=coord.device)
+    nvox = frag["index"].shape[1]
+    off = torch.tensor([nvox], device=coord.device)
+    for p in range(frag["index"].shape[0]):
+        idx = frag["index"][p]
+        inp = dict(coord=coord[idx], grid_coord=frag["grid_coord"], feat=feat[idx].contiguous(), offset=off)
+        f = model(inp, chunk_size=chunk_size)["point_feat"]["feat"]
+        nv.feat_text_scan(f, text, want_max=False, idx=idx.to(torch.int32).contiguous(), pred_accum=pred)
+    if topk is not None:
+        return pred.topk(int(topk), dim=1)[1], pred
+    mx, am = pred.max(1)
+    am = am.clone()
+    am[mx < confidence_threshold] = ignore_index
+    return am, pred
+
+
 def _take_rows(t, idx32):
     """t[idx] for a per-point tensor: wide contiguous rows go through the library's row-gather kernel."""
     if t.dim() == 2 and t.is_contiguous() and (t.shape[1] * t.element_size()) % 16 == 0 and t.dtype in (torch.float32, torch.bfloat16, torch.float16):

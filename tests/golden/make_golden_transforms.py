@@ -63,6 +63,12 @@ def main():
     # the kept coordinate of every voxel lies in that voxel (self-check of the recorded run)
     assert np.array_equal(np.floor(out["coord"] / 0.1).astype(int) - np.floor(d["coord"] / 0.1).astype(int).min(0), gc)
 
+    # ---- GridSample(test): the tester's fragment generator (transform.py:1302-1330) on the same sample ----
+    parts = T.GridSample(grid_size=0.1, hash_type="fnv", mode="test", keys=keys, return_grid_coord=True)(dict(d))
+    fx["gst_nparts"] = np.int64(len(parts))
+    fx["gst_index"] = np.stack([p_["index"] for p_ in parts]).astype(np.int32)            # (parts, n_vox): the `index` of every fragment
+    assert all(np.array_equal(p_["grid_coord"], parts[0]["grid_coord"]) for p_ in parts) and fx["gst_index"].shape[1] == len(gc)
+
     # ---- SphereCrop: center (deterministic) and random (centre replayed) ----
     d = sample(5000, 2)
     fx["sc_seed"], fx["sc_n"], fx["sc_point_max"] = np.int64(2), np.int64(5000), np.int64(1800)

@@ -89,3 +89,87 @@ def test_collect_and_point_collate_match_the_reference(fx):
     gc = out["grid_coord"] - out["grid_coord"].amin(0, keepdim=True)
     plan = build_plan(gc.cuda(), out["offset"].cuda(), ("z", "hilbert"), (2,))
     assert plan.levels[0].n == int(fx["pc_sizes"][:3].sum())
+
+
+def test_grid_sample_test_fragments_cover_the_reference_partition(fx):
+    """GridSample(mode="test") (transform.py:1302-1330): as many fragments as the fullest voxel has points, each holding ONE
+    point per occupied voxel, together covering every point; fragment i takes member (i mod c) of a voxel with c points.  The
+    reference's numpy argsort leaves the order INSIDE a voxel unspecified, so the recorded run is compared per voxel: the
+    same member set, enumerated cyclically with the same period."""
+    from scenesplat_amd.gpu_transforms import grid_sample_test
+    d = _sample(int(fx["gs_n"]), int(fx["gs_seed"]))
+    out = grid_sample_test(torch.from_numpy(d["coord"]).cuda(), float(fx["gs_grid"]), return_inverse=True)
+    idx = out["index"].cpu().numpy()
+    ref = fx["gst_index"]
+    assert idx.shape == ref.shape == (int(fx["gst_nparts"]), int(fx["gs_n_out"]))
+    inv = out["inverse"].cpu().numpy()                       # our voxel id per point
+    cnt = out["count"].cpu().numpy()
+    assert cnt.max() == idx.shape[0] and np.array_equal(np.bincount(inv), cnt)
+    assert np.array_equal(np.sort(np.unique(idx)), np.arange(len(inv)))            # every point is in some fragment
+    for p in range(idx.shape[0]):
+        assert np.array_equal(inv[idx[p]], np.arange(idx.shape[1]))                 # fragment p: one member of every voxel, in voxel order
+    # cyclic enumeration in row order: member (p mod c) of the voxel's ascending rows
+    members = [np.nonzero(inv == v)[0] for v in range(40)]
+    for v, m in enumerate(members):
+        assert [int(idx[p, v]) for p in range(idx.shape[0])] == [int(m[p % len(m)]) for p in range(idx.shape[0])]
+    # the reference's fragments: same voxels (its own numbering), per voxel the same member set with the same period
+    rinv = fx["gs_inverse"]                                    # reference voxel id per point
+    for p in range(ref.shape[0]):
+        assert np.array_equal(np.sort(rinv[ref[p]]), np.arange(ref.shape[1]))
+    ours_of = {}                                               # our voxel -> the set of its members over the fragments
+    for v in range(idx.shape[1]):
+        ours_of[frozenset(idx[:, v].tolist())] = cnt[v]
+    rcol = np.argsort(rinv[ref[0]])                            # reference columns by reference voxel id
+    for c_ in rcol[:500]:
+        col = ref[:, c_]
+        key = frozenset(col.tolist())
+        assert key in ours_of                                  # the same member set as one of our voxels
+        c = ours_of[key]
+        assert all(col[p] == col[p % c] for p in range(len(col)))                    # period = the voxel's point count
+    gc = out["grid_coord"].cpu().numpy()
+    order = np.lexsort((gc[:, 2], gc[:, 1], gc[:, 0]))
+    assert np.array_equal(gc[order], fx["gs_grid_coord_sorted"])
+
+
+def test_open_vocab_fragment_loop_equals_the_plain_torch_loop():
+    """engines/test.py:300-378 on the device (gpu_transforms.open_vocab_fragments): fragments -> chunked forward -> fused
+    scan + accumulate -> top-3 (ScanNet++ form) or arg-max with the confidence threshold, against the same loop written with
+    torch.mm / sigmoid / index_add on the fragments' features."""
+    from scenesplat_amd.gpu_transforms import grid_sample_test, open_vocab_fragments
+    from scenesplat_amd.pointcept_api import MODELS
+    from scenesplat_amd.synthetic import room_chunk
+    cfg = dict(in_channels=11, order=("z", "z-trans", "hilbert", "hilbert-trans"), stride=(2, 2), enc_depths=(1, 1, 1), enc_channels=(16, 32, 48),
+               enc_num_head=(1, 2, 3), enc_patch_size=(64, 64, 16), dec_depths=(1, 1), dec_channels=(48, 32), dec_num_head=(1, 2), dec_patch_size=(64, 64),
+               shuffle_orders=False)
+    torch.manual_seed(0)
+    model = MODELS.build(dict(type="LangPretrainer", backbone=dict(type="PT-v3m1", **cfg), criteria=[])).cuda().eval()
+    # (SerializedPooling shuffles its curves with the host RNG: seeded before every loop below)
+    d = room_chunk(n_side=32, seed=2, lang_dim=0)
+    g = torch.Generator().manual_seed(4)
+    # three Gaussians per voxel on a part of the room, two / one elsewhere: 3 fragments
+    coord = torch.cat([d["coord"], d["coord"][:900] + 0.004, d["coord"][:300] + 0.008]).cuda()
+    feat = torch.cat([d["feat"], d["feat"][:900] * 0.9, d["feat"][:300] * 1.1]).cuda()
+    text = torch.nn.functional.normalize(torch.randn(20, 48, generator=g), dim=1).cuda()
+    frag = grid_sample_test(coord, 0.02)
+    assert frag["index"].shape[0] == 3
+    torch.manual_seed(9)
+    top3, pred = open_vocab_fragments(model, dict(coord=coord, feat=feat), text, 0.02, topk=3)
+    torch.manual_seed(9)
+    lab, pred2 = open_vocab_fragments(model, dict(coord=coord, feat=feat), text, 0.02, confidence_threshold=0.55)
+    assert torch.equal(pred, pred2)
+    # the plain loop on the same fragments
+    ref = torch.zeros_like(pred)
+    torch.manual_seed(9)
+    with torch.no_grad():
+        for p in range(3):
+            idx = frag["index"][p]
+            f = model(dict(coord=coord[idx], grid_coord=frag["grid_coord"], feat=feat[idx].contiguous(), offset=torch.tensor([len(idx)]).cuda()),
+                      chunk_size=600000)["point_feat"]["feat"]
+            ref.index_add_(0, idx, torch.sigmoid(f.to(torch.bfloat16).float() @ text.to(torch.bfloat16).float().t()))
+    assert torch.allclose(pred, ref, atol=2e-3, rtol=1e-3)
+    assert float((pred.sum(1) > 0).float().mean()) == 1.0       # every Gaussian was in some fragment
+    # top-3 and thresholded arg-max follow from pred
+    assert torch.equal(top3, pred.topk(3, dim=1)[1])
+    mx, am = pred.max(1)
+    exp = am.clone(); exp[mx < 0.55] = -1
+    assert torch.equal(lab, exp) and int((lab == -1).sum()) > 0 and int((lab >= 0).sum()) > 0
