@@ -542,30 +542,37 @@ extern "C" int ss_bfs_cluster(const int32_t* semantic_label, const int32_t* ball
 // out[i] = most frequent valid label among labels[nn_idx[i][0..k)], ties -> smallest label,
 // ignore_label when no neighbour carries a valid label.  k <= 64.
 // ---------------------------------------------------------------------------------------------
+// Cooperative form (round 4): a group of G = 32 (k <= 32) or 64 lanes owns one point; lane j loads neighbour j's label (coalesced
+// index reads, no per-thread label array in scratch), counts its label among the group with k shuffles, and the group reduces to the
+// label with the largest count (ties: the smallest label).  The thread-per-point form took 0.83 ms for 1,000,000 points x k = 25.
+template <int G>
 __global__ void k_majority_vote(const int32_t* __restrict__ nn_idx, const int32_t* __restrict__ labels, int64_t m, int k,
                                 int ignore_label, int num_classes, int32_t* __restrict__ out) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  int lab[64];
-  for (int j = 0; j < k; ++j) {
-    int id = nn_idx[i * k + j];
-    int l = id >= 0 ? labels[id] : ignore_label;
-    lab[j] = (l != ignore_label && l >= 0 && l < num_classes) ? l : -1;
+  const int lane = threadIdx.x & 63, j = lane & (G - 1), base = lane & ~(G - 1);
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;       // point of this group (uniform inside the group)
+  const bool live = i < m;
+  int l = -1;
+  if (live && j < k) {
+    const int id = nn_idx[i * k + j];
+    const int v = id >= 0 ? labels[id] : ignore_label;
+    l = (v != ignore_label && v >= 0 && v < num_classes) ? v : -1;
   }
-  int best = ignore_label, best_cnt = 0;
-  for (int j = 0; j < k; ++j) {
-    int l = lab[j];
-    if (l < 0) continue;
-    int c = 0;
-    for (int q = 0; q < k; ++q) c += (lab[q] == l);
-    if (c > best_cnt || (c == best_cnt && l < best)) { best_cnt = c; best = l; }
+  int c = 0;
+  for (int q = 0; q < k; ++q) c += (__shfl(l, base + q, 64) == l);
+  // key: larger count first, then smaller label; invalid lanes lose
+  long long key = l >= 0 ? (((long long)c << 32) | (unsigned)(0x7fffffff - l)) : -1LL;
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1) {
+    const long long other = __shfl_xor(key, o, 64);
+    key = other > key ? other : key;
   }
-  out[i] = best;
+  if (live && j == 0) out[i] = key >= 0 ? 0x7fffffff - (int)(key & 0xffffffffLL) : ignore_label;
 }
 extern "C" int ss_majority_vote(const int32_t* nn_idx, const int32_t* labels, int64_t m, int k, int ignore_label,
                                 int num_classes, int32_t* out, hipStream_t stream) {
   if (m < 0 || k < 1 || k > 64 || num_classes < 1) return SS_ERR_ARG;
   if (m == 0) return SS_OK;
-  SS_LAUNCH(k_majority_vote, dim3(ss_div_up(m, 128)), dim3(128), 0, stream, nn_idx, labels, m, k, ignore_label, num_classes, out);
+  if (k <= 32) SS_LAUNCH(k_majority_vote<32>, dim3(ss_div_up(m * 32, 256)), dim3(256), 0, stream, nn_idx, labels, m, k, ignore_label, num_classes, out);
+  else SS_LAUNCH(k_majority_vote<64>, dim3(ss_div_up(m * 64, 256)), dim3(256), 0, stream, nn_idx, labels, m, k, ignore_label, num_classes, out);
   return SS_OK;
 }

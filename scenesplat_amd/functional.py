@@ -847,8 +847,11 @@ class _QkvWindowAttentionHM(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None
 
 
-HM_FUSED_MIN_ROWS = int(os.environ.get("SS_HM_FUSED_MIN_ROWS", "4096"))        # below: fp32 library GEMM + pack kernel
-HM_FUSED_MIN_CHANNELS = int(os.environ.get("SS_HM_FUSED_MIN_CHANNELS", "128"))
+# below these: fp32 library GEMM + bias add + pack kernel (3 launches).  Round 4: 1,024 rows / 64 channels instead of 4,096 / 128 -- the
+# fused epilogue also on enc3 (1,600 x 256, 6 blocks) and enc1 (25,600 x 64): two launches fewer per block, -0.08 ms each in the
+# in-process A/B (scripts/ab_step.py hm_rows | hm_ch: 37.10 vs 37.18, 36.94 vs 37.02 ms/step)
+HM_FUSED_MIN_ROWS = int(os.environ.get("SS_HM_FUSED_MIN_ROWS", "1024"))
+HM_FUSED_MIN_CHANNELS = int(os.environ.get("SS_HM_FUSED_MIN_CHANNELS", "64"))
 
 
 def qkv_window_attention(x, weight, bias, win, num_heads, scale):

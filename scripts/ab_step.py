@@ -56,6 +56,10 @@ def setter(on):
         SF.CONV_WALK_RULEBOOK = on
     elif which == "gelu":
         SF.GELU_HIP = on
+    elif which == "hm_rows":          # the qkv projection's head-major epilogue also on levels of 1,024 .. 4,095 rows (enc3: 1,600)
+        SF.HM_FUSED_MIN_ROWS = 1024 if on else 4096
+    elif which == "hm_ch":            # ... and from 64 channels on (enc1: 25,600 x 64)
+        SF.HM_FUSED_MIN_CHANNELS = 64 if on else 128
     elif which == "mask_small":
         import scenesplat_amd.plan as P
         P.CONV_MASK_MIN_SITES = 4096 if on else 16384

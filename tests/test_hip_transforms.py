@@ -151,7 +151,8 @@ def test_open_vocab_fragment_loop_equals_the_plain_torch_loop():
     feat = torch.cat([d["feat"], d["feat"][:900] * 0.9, d["feat"][:300] * 1.1]).cuda()
     text = torch.nn.functional.normalize(torch.randn(20, 48, generator=g), dim=1).cuda()
     frag = grid_sample_test(coord, 0.02)
-    assert frag["index"].shape[0] == 3
+    P = frag["index"].shape[0]
+    assert P >= 3                                               # (the shifted copies also land in neighbouring voxels)
     torch.manual_seed(9)
     top3, pred = open_vocab_fragments(model, dict(coord=coord, feat=feat), text, 0.02, topk=3)
     torch.manual_seed(9)
@@ -161,7 +162,7 @@ def test_open_vocab_fragment_loop_equals_the_plain_torch_loop():
     ref = torch.zeros_like(pred)
     torch.manual_seed(9)
     with torch.no_grad():
-        for p in range(3):
+        for p in range(P):
             idx = frag["index"][p]
             f = model(dict(coord=coord[idx], grid_coord=frag["grid_coord"], feat=feat[idx].contiguous(), offset=torch.tensor([len(idx)]).cuda()),
                       chunk_size=600000)["point_feat"]["feat"]
