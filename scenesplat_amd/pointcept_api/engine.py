@@ -334,6 +334,8 @@ class Trainer(TrainerBase):
             # round 3: the gradient average of DDP (engines/defaults.py:13-34) as one all-reduce per model STAGE, launched when the
             # stage's gradients become final in the backward pass (scenesplat_amd/grad_exchange.py); no wrapper, no bucket copies.
             # Same initial weights on every rank, as DDP's constructor broadcast enforces:
+            # cfg.find_unused_parameters needs no counterpart here: the stage all-reduces are issued in a FIXED order whatever
+            # gradients arrive (grad_exchange.py), and a parameter that took no part in a step is reduced as zeros.
             from ..grad_exchange import StageGradExchange
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0)
