@@ -382,6 +382,13 @@ int ss_knn_grid_build(const float* xyz, const int64_t* sorted_keys, const int32_
 int ss_knn_grid_query(int m, int nsample, const float* new_xyz, const int32_t* qorder, const int32_t* offset, const int32_t* new_offset,
                       int num_batches, float origin_x, float origin_y, float origin_z, float cell_size, int dimx, int dimy, int dimz,
                       int64_t n, const void* workspace, int32_t* idx, float* dist2, ss_stream_t stream);
+/* ss_ball_query's result on the grid built by ss_knn_grid_build (libs/pointops/src/ball_query/ball_query_cuda_kernel.cu:58-123): one wave
+ * per query collects the candidates of the cells within the ball's reach into LDS, sorts them there and writes all of them or the
+ * strided subsample; max_radius <= 8 cells.  xyz = the original coordinates (crowded balls fall back to the index-order rule). */
+int ss_ball_grid_query(int m, int nsample, float min_radius, float max_radius, const float* xyz, const float* new_xyz,
+                       const int32_t* qorder, const int32_t* offset, const int32_t* new_offset, int num_batches, float origin_x,
+                       float origin_y, float origin_z, float cell_size, int dimx, int dimy, int dimz, int64_t n, const void* workspace,
+                       int32_t* idx, float* dist2, ss_stream_t stream);
 /* neighbour majority vote of the zero-shot evaluator (pointcept/utils/misc.py:17-51): ties -> smallest label, k <= 64 */
 int ss_majority_vote(const int32_t* nn_idx, const int32_t* labels, int64_t m, int k, int ignore_label, int num_classes,
                      int32_t* out, ss_stream_t stream);

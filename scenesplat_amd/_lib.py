@@ -114,6 +114,7 @@ PROTOTYPES = {
     "ss_knn_grid_keys": (c_i, [c_p, c_p, c_i, c_i64, c_f, c_f, c_f, c_f, c_p, c_p]),
     "ss_knn_grid_build": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_sz, c_p, c_p]),
     "ss_knn_grid_query": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i64, c_p, c_p, c_p, c_p]),
+    "ss_ball_grid_query": (c_i, [c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i64, c_p, c_p, c_p, c_p]),
     "ss_knn_query": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
     "ss_ball_query_workspace_bytes": (c_sz, [c_i]),
     "ss_ball_query": (c_i, [c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_sz, c_p]),

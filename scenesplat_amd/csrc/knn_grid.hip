@@ -299,3 +299,139 @@ extern "C" int ss_knn_grid_query(int m, int nsample, const float* new_xyz, const
             num_batches, ox, oy, oz, cell, 1.0f / cell, dimx, dimy, dimz, table, (unsigned)(ts - 1), pts, idx, dist2);
   return SS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Ball query on the same grid (round 4).  Result of ss_ball_query (libs/pointops/src/ball_query/ball_query_cuda_kernel.cu:58-123 with
+// this library's documented fixes: true nearest-first order, real squared distances): the candidates with d2 <= 1e-5 or
+// min2 <= d2 < max2 -- at most 2048, the FIRST 2048 in index order when there are more --, sorted ascending; all of them
+// (-1 / 1e10 padding) when they fit nsample, else the strided subsample  sorted[(int)(i * num / nsample)].
+// One wave per query: candidates of the cells within the ball's reach are appended to a per-wave LDS list (ballot + prefix),
+// sorted there by a bitonic network run by the wave, and written out.  The brute-force kernel keeps a 16-KiB candidate list per
+// query in global memory and heap-sorts it with one thread.  More than 2048 candidates (a radius far beyond the cell size): the wave
+// re-collects by scanning the batch element in index order, which is exactly the reference's rule.
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define KB_CAP 2048
+
+__device__ __forceinline__ bool kb_pass(float d2, float min2, float max2) { return d2 <= 1e-5f || (d2 >= min2 && d2 < max2); }
+
+__global__ void __launch_bounds__(KG_THREADS)
+k_kg_ball(int m, int nsample, float min2, float max2, const float* __restrict__ new_xyz, const int32_t* __restrict__ qorder,
+          const int32_t* __restrict__ offset, const int32_t* __restrict__ new_offset, int nb, float ox, float oy, float oz, float h,
+          float inv_h, int dimx, int dimy, int dimz, const KgCell* __restrict__ table, unsigned mask, const float4* __restrict__ pts,
+          const float* __restrict__ xyz, int32_t* __restrict__ idx, float* __restrict__ dist2) {
+  __shared__ float cd_s[KG_WAVES][KB_CAP];
+  __shared__ int ci_s[KG_WAVES][KB_CAP];
+  __shared__ int pre_s[KG_WAVES][64];
+  __shared__ int start_s[KG_WAVES][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int w = blockIdx.x * KG_WAVES + wv;
+  if (w >= m) return;                                                   // wave-uniform
+  const int q = qorder ? qorder[w] : w;
+  const float qx = new_xyz[3 * q], qy = new_xyz[3 * q + 1], qz = new_xyz[3 * q + 2];
+  const int b = kg_batch_of(q, new_offset, nb);
+  const int seg0 = b == 0 ? 0 : offset[b - 1], seg1 = offset[b];
+  const int cx = kg_cell(qx, ox, inv_h), cy = kg_cell(qy, oy, inv_h), cz = kg_cell(qz, oz, inv_h);
+  float* const cd = cd_s[wv]; int* const ci = ci_s[wv];
+  // every point with d2 < max2 lies within R rings (one more than max_r / h: the query sits anywhere in its cell; + rounding slack)
+  const int R = (int)ceilf(sqrtf(max2) * inv_h + 1e-3f) + 0;
+  const int side = 2 * R + 1, ncell = side * side * side;
+  int num = 0;                                                          // wave-uniform
+  bool overflow = false;
+  for (int base = 0; base < ncell && !overflow; base += 64) {
+    const int e = base + lane;
+    int cnt = 0, st = 0;
+    if (e < ncell) {
+      const int dx = e / (side * side) - R, rem = e % (side * side), dy = rem / side - R, dz = rem % side - R;
+      const int X = cx + dx, Y = cy + dy, Z = cz + dz;
+      if (X >= 0 && Y >= 0 && Z >= 0 && X <= dimx && Y <= dimy && Z <= dimz) {
+        const long long key = ((long long)b << 48) | ((long long)X << 32) | ((long long)Y << 16) | (long long)Z;
+        unsigned hh = kg_hash(key) & mask;
+        while (true) {
+          const KgCell c = table[hh];
+          if (c.key == key) { st = c.start; cnt = c.end - c.start; break; }
+          if (c.key == -1LL) break;
+          hh = (hh + 1) & mask;
+        }
+      }
+    }
+    if (!__ballot(cnt > 0)) continue;
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+    const int total = __shfl(inc, 63, 64);
+    pre_s[wv][lane] = inc - cnt; start_s[wv][lane] = st;
+    for (int tt = 0; tt < total && !overflow; tt += 64) {
+      const int t = tt + lane;
+      float d2 = 0.f; int oi = -1; bool ok = false;
+      if (t < total) {
+        int lo = 0;
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) if (pre_s[wv][lo + s] <= t) lo += s;
+        const float4 pt = pts[start_s[wv][lo] + (t - pre_s[wv][lo])];
+        d2 = po_dist2(qx, qy, qz, pt.x, pt.y, pt.z); oi = __float_as_int(pt.w);
+        ok = kb_pass(d2, min2, max2);
+      }
+      const unsigned long long bm = __ballot(ok);
+      const int add = __popcll(bm);
+      if (num + add > KB_CAP) { overflow = true; break; }
+      if (ok) { const int p = num + __popcll(bm & ((1ull << lane) - 1ull)); cd[p] = d2; ci[p] = oi; }
+      num += add;
+    }
+  }
+  if (overflow) {
+    // the reference's rule for crowded balls: the first KB_CAP candidates in INDEX order (original coordinates, index order)
+    num = 0;
+    for (int p0 = seg0; p0 < seg1 && num < KB_CAP; p0 += 64) {
+      const int p = p0 + lane;
+      float d2 = 0.f; bool ok = false;
+      if (p < seg1) { d2 = po_dist2(qx, qy, qz, xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]); ok = kb_pass(d2, min2, max2); }
+      const unsigned long long bm = __ballot(ok);
+      const int rank = num + __popcll(bm & ((1ull << lane) - 1ull));
+      if (ok && rank < KB_CAP) { cd[rank] = d2; ci[rank] = p; }
+      num = min(KB_CAP, num + __popcll(bm));
+    }
+  }
+  // bitonic sort of the list (padded with +inf to a power of two) in LDS, ascending by (d2, index)
+  int np2 = 64;
+  while (np2 < num) np2 <<= 1;
+  for (int e = num + lane; e < np2; e += 64) { cd[e] = KG_INF; ci[e] = 0x7fffffff; }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+  for (int size = 2; size <= np2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int e = lane; e < (np2 >> 1); e += 64) {
+        const int lo = ((e & ~(stride - 1)) << 1) | (e & (stride - 1)), hi = lo | stride;
+        const bool up = (lo & size) == 0;
+        const float a = cd[lo], bb = cd[hi]; const int ia = ci[lo], ib = ci[hi];
+        const bool swap = up ? kg_less(bb, ib, a, ia) : kg_less(a, ia, bb, ib);
+        if (swap) { cd[lo] = bb; cd[hi] = a; ci[lo] = ib; ci[hi] = ia; }
+      }
+      __builtin_amdgcn_wave_barrier();          // the next stage reads what other lanes of this wave just wrote (LDS is in order per wave)
+      asm volatile("" ::: "memory");
+    }
+  }
+  int32_t* const oi_ = idx + (int64_t)q * nsample; float* const od = dist2 + (int64_t)q * nsample;
+  if (num <= nsample) {
+    for (int i = lane; i < nsample; i += 64) { oi_[i] = i < num ? ci[i] : -1; od[i] = i < num ? cd[i] : 1e10f; }
+  } else {
+    const float sep = (float)num / nsample;
+    for (int i = lane; i < nsample; i += 64) { const int k = (int)(sep * i); oi_[i] = ci[k]; od[i] = cd[k]; }
+  }
+}
+
+extern "C" int ss_ball_grid_query(int m, int nsample, float min_radius, float max_radius, const float* xyz, const float* new_xyz,
+                                  const int32_t* qorder, const int32_t* offset, const int32_t* new_offset, int num_batches, float ox,
+                                  float oy, float oz, float cell, int dimx, int dimy, int dimz, int64_t n, const void* workspace,
+                                  int32_t* idx, float* dist2, hipStream_t stream) {
+  if (m < 0 || nsample < 1 || num_batches < 1 || n < 0 || !(cell > 0.f) || !(min_radius < max_radius) || dimx < 0 || dimy < 0 || dimz < 0 ||
+      dimx > 65535 || dimy > 65535 || dimz > 65535 || max_radius / cell > 8.f)
+    return SS_ERR_ARG;
+  if (m == 0) return SS_OK;
+  const int64_t ts = ss_knn_grid_table_size(n);
+  const KgCell* table = (const KgCell*)workspace;
+  const float4* pts = (const float4*)((const char*)workspace + 16 * ts);
+  SS_LAUNCH(k_kg_ball, dim3(ss_div_up(m, KG_WAVES)), dim3(KG_THREADS), 0, stream, m, nsample, min_radius * min_radius,
+            max_radius * max_radius, new_xyz, qorder, offset, new_offset, num_batches, ox, oy, oz, cell, 1.0f / cell, dimx, dimy, dimz, table,
+            (unsigned)(ts - 1), pts, xyz, idx, dist2);
+  return SS_OK;
+}

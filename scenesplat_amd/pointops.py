@@ -63,7 +63,7 @@ def knn_query(nsample, xyz, offset, new_xyz=None, new_offset=None, impl="auto"):
     return idx, torch.sqrt(d2)
 
 
-def _knn_grid(nsample, xyz, off, new_xyz, noff, self_query, cell=None, return_info=False):
+def _knn_grid(nsample, xyz, off, new_xyz, noff, self_query, cell=None, return_info=False, ball=None):
     """Build the hash grid over xyz (cell size from the data: ~2/3 nsample points per OCCUPIED cell, refined at most twice from
     the occupied-cell count the build reports) and run the ring search.  Host reads: the bounding box and that count."""
     import ctypes
@@ -77,7 +77,7 @@ def _knn_grid(nsample, xyz, off, new_xyz, noff, self_query, cell=None, return_in
         h = max((ext[0] * ext[1] * ext[2] / max(n, 1) * target) ** (1.0 / 3.0), max(ext) / 60000.0, 1e-6)
         tries = 3
     else:
-        h, tries = float(cell), 1
+        h, tries = max(float(cell), max(ext) / 60000.0), 1
     ws = nv._ws(lib.ss_knn_grid_workspace_bytes(n), dev)
     keys = torch.empty((1, n), dtype=torch.int64, device=dev)
     ncell = torch.empty(1, dtype=torch.int32, device=dev)
@@ -107,6 +107,10 @@ def _knn_grid(nsample, xyz, off, new_xyz, noff, self_query, cell=None, return_in
         qorder = nv.argsort_i64(qkeys, 63, want_inverse=False, want_sorted=False)[0][0]
     idx = torch.empty((m, nsample), dtype=torch.int32, device=dev)
     d2 = torch.empty((m, nsample), dtype=torch.float32, device=dev)
+    if ball is not None:
+        check(lib.ss_ball_grid_query(m, nsample, ball[0], ball[1], _p(xyz), _p(new_xyz), _p(qorder), _p(off), _p(noff), nb, origin[0], origin[1],
+                                     origin[2], h, dims[0], dims[1], dims[2], n, _p(ws), _p(idx), _p(d2), _s()), "ss_ball_grid_query")
+        return idx, d2
     check(lib.ss_knn_grid_query(m, nsample, _p(new_xyz), _p(qorder), _p(off), _p(noff), nb, origin[0], origin[1], origin[2], h,
                                 dims[0], dims[1], dims[2], n, _p(ws), _p(idx), _p(d2), _s()), "ss_knn_grid_query")
     if return_info:
@@ -114,13 +118,20 @@ def _knn_grid(nsample, xyz, off, new_xyz, noff, self_query, cell=None, return_in
     return idx, d2
 
 
-def ball_query(nsample, max_radius, min_radius, xyz, offset, new_xyz=None, new_offset=None):
-    if new_xyz is None or new_offset is None:
+def ball_query(nsample, max_radius, min_radius, xyz, offset, new_xyz=None, new_offset=None, impl="auto"):
+    """impl: "brute" = one thread per query scanning its batch element (the reference's algorithm); "grid" = one wave per query on the
+    hash grid of csrc/knn_grid.hip (cell = max_radius: 27 cells hold the ball); "auto" = grid from KNN_GRID_MIN_POINTS candidates on.
+    Same result (candidates sorted ascending; equal distances: the smaller index first)."""
+    self_query = new_xyz is None or new_offset is None
+    if self_query:
         new_xyz, new_offset = xyz, offset
     assert min_radius < max_radius
     xyz, new_xyz = _f(xyz, "xyz"), _f(new_xyz, "new_xyz")
     off, noff = _i(offset, "offset"), _i(new_offset, "new_offset")
     m = new_xyz.shape[0]
+    if impl == "grid" or (impl == "auto" and xyz.shape[0] >= KNN_GRID_MIN_POINTS):
+        idx, d2 = _knn_grid(nsample, xyz, off, new_xyz, noff, self_query, cell=float(max_radius), ball=(float(min_radius), float(max_radius)))
+        return idx, torch.sqrt(d2)
     idx = torch.empty((m, nsample), dtype=torch.int32, device=xyz.device)
     d2 = torch.empty((m, nsample), dtype=torch.float32, device=xyz.device)
     ws = nv._ws(nv.lib().ss_ball_query_workspace_bytes(m), xyz.device)

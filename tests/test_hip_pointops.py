@@ -319,3 +319,29 @@ def test_neighbor_voting_on_the_grid_matches_brute_force_and_scales():
     out = po.neighbor_voting(cu(big), lab, val, 25, -1, 160)
     torch.cuda.synchronize()
     assert out.shape == (nb,) and int(out.min()) >= 0 and int(out.max()) < 160
+
+
+@pytest.mark.parametrize("case", ["room", "uniform2", "crowded", "queries_outside"])
+def test_ball_query_on_the_grid_equals_the_brute_force_kernel(case):
+    """ss_ball_grid_query (one wave per query, candidates sorted in LDS) against ss_ball_query (one thread per query, 16 KiB of global
+    scratch each): identical indices and squared distances -- all candidates when they fit nsample, the strided subsample of the
+    sorted list otherwise, and the reference's first-2048-in-index-order rule when a ball holds more than 2048 candidates."""
+    from scenesplat_amd import pointops as po
+    g = np.random.default_rng(11)
+    new_xyz = noff = None
+    if case == "room":
+        xyz, off = _room_cloud(96, 1, batch=2); ns, rmax, rmin = 16, 0.1, 0.0
+    elif case == "uniform2":
+        xyz = g.random((15000, 3), dtype=np.float32); off = np.array([9000, 15000]); ns, rmax, rmin = 32, 0.08, 0.02
+    elif case == "crowded":
+        xyz = (g.random((12000, 3), dtype=np.float32) * 0.2).astype(np.float32); off = np.array([12000]); ns, rmax, rmin = 24, 0.15, 0.0   # > 2048 candidates per ball
+    else:
+        xyz, off = _room_cloud(64, 2); ns, rmax, rmin = 8, 0.07, 0.01
+        new_xyz = np.concatenate([xyz[:2000] + 0.003, g.random((300, 3), dtype=np.float32) * 6 - 2]).astype(np.float32); noff = np.array([len(new_xyz)])
+    args = (cu(xyz), cu(off)) + (() if new_xyz is None else (cu(new_xyz), cu(noff)))
+    bi, bd = po.ball_query(ns, rmax, rmin, *args, impl="brute")
+    gi, gd = po.ball_query(ns, rmax, rmin, *args, impl="grid")
+    assert torch.equal(gi, bi), (case, int((gi != bi).sum()))
+    assert torch.equal(gd, bd)
+    if case == "crowded":
+        assert int((bi >= 0).all(1).sum()) == len(bi)            # every ball overflows nsample: the strided subsample everywhere
