@@ -452,8 +452,10 @@ def pointops_lines(log):
         ms = best_ms(lambda: po.neighbor_voting(big, lab, val, 25, -1, 160))
         out["neighbor_voting_1m_k25"] = dict(ms=ms, gaussians_per_s=nb / ms * 1e3, what="evaluator.py:697-739: kNN (k = 25) among the 90 % valid Gaussians for all 1,000,000 + majority vote (reference: CPU cKDTree + numba)")
         log("pointops: neighbor voting, 1,000,000 Gaussians, k=25: %.2f ms" % ms)
-        ms = best_ms(lambda: po.ball_query(16, 0.1, 0.0, small, off), reps=2)
-        out["ball_query_16_r0.1_102400"] = dict(ms=ms, queries_per_s=n / ms * 1e3, what="ball_query nsample 16, radius 0.1 m (brute-force scan with per-query candidate scratch)")
+        ms = best_ms(lambda: po.ball_query(16, 0.1, 0.0, small, off, impl="brute"), reps=2)
+        out["ball_query_16_r0.1_brute_102400"] = dict(ms=ms, queries_per_s=n / ms * 1e3, what="ball_query nsample 16, radius 0.1 m: the reference's algorithm (one thread per query scanning its batch element, 16 KiB of candidate scratch each)")
+        ms = best_ms(lambda: po.ball_query(16, 0.1, 0.0, small, off, impl="grid"))
+        out["ball_query_16_r0.1_102400"] = dict(ms=ms, queries_per_s=n / ms * 1e3, what="the same result on the hash grid (one wave per query, candidates sorted in LDS), incl. grid build")
         noff = torch.tensor([n // 4], dtype=torch.int32, device="cuda")
         ms = best_ms(lambda: po.farthest_point_sampling(small, off, noff), reps=1)
         out["fps_102400_to_25600"] = dict(ms=ms, samples_per_s=(n // 4) / ms * 1e3, what="farthest point sampling 102,400 -> 25,600 (one workgroup per batch element, sequential by definition)")
@@ -466,7 +468,8 @@ def pointops_lines(log):
         by = n * 16 * 64 * 4
         out["grouping_16x64_102400"] = dict(fwd_ms=ms_f, fwd_GBps=(by + n * 64 * 4) / ms_f / 1e6, bwd_ms=ms_b, bwd_GBps=(by + n * 64 * 4) / max(ms_b, 1e-3) / 1e6,
                                             what="grouping (gather of 16 neighbour rows of 64 fp32 channels) forward / backward (fp32 atomics)")
-        log("pointops: ball %.2f ms, fps %.1f ms, grouping fwd %.3f / bwd %.3f ms" % (out["ball_query_16_r0.1_102400"]["ms"], out["fps_102400_to_25600"]["ms"], ms_f, ms_b))
+        log("pointops: ball grid %.2f ms (brute %.2f), fps %.1f ms, grouping fwd %.3f / bwd %.3f ms" % (
+            out["ball_query_16_r0.1_102400"]["ms"], out["ball_query_16_r0.1_brute_102400"]["ms"], out["fps_102400_to_25600"]["ms"], ms_f, ms_b))
     except Exception as e:  # noqa: BLE001  (secondary lines must never take the headline down)
         log("pointops lines: %s: %s" % (type(e).__name__, e))
         out["error"] = "%s: %s" % (type(e).__name__, e)

@@ -22,7 +22,9 @@ lab = torch.randint(0, 160, (nb,), device="cuda", generator=g).int()
 val = torch.rand(nb, device="cuda", generator=g) < 0.9
 for _ in range(3):
     po.neighbor_voting(big, lab, val, 25, -1, 160)
-po.ball_query(16, 0.1, 0.0, small, off)
+po.ball_query(16, 0.1, 0.0, small, off, impl="brute")
+for _ in range(3):
+    po.ball_query(16, 0.1, 0.0, small, off, impl="grid")
 po.farthest_point_sampling(small, off, torch.tensor([n // 4], dtype=torch.int32, device="cuda"))
 idx, _ = po.knn_query(16, small, off, impl="grid")
 feat = torch.randn(n, 64, device="cuda", generator=g).requires_grad_(True)
