@@ -30,12 +30,15 @@ __device__ __forceinline__ int po_batch_of(int i, const int32_t* __restrict__ of
 // ---------------------------------------------------------------------------------------------
 // KNN (knn_query_cuda_kernel.cu:60-104): K nearest of the same batch element, ascending, -1 / 1e10 pad
 // ---------------------------------------------------------------------------------------------
+// max-heap on (distance, index): equal distances are ordered by index, so the sorted output is fully determined (the reference's heap
+// leaves ties in no particular order; the grid kernels of knn_grid.hip use the same total order)
+__device__ __forceinline__ bool po_greater(float da, int ia, float db, int ib) { return da > db || (da == db && ia > ib); }
 template <int K>
 __device__ __forceinline__ void heap_down(float* d, int* ix, int root, int n) {
   int child = 2 * root + 1;
   while (child < n) {
-    if (child + 1 < n && d[child + 1] > d[child]) child++;
-    if (d[root] > d[child]) return;
+    if (child + 1 < n && po_greater(d[child + 1], ix[child + 1], d[child], ix[child])) child++;
+    if (po_greater(d[root], ix[root], d[child], ix[child])) return;
     float td = d[root]; d[root] = d[child]; d[child] = td;
     int ti = ix[root]; ix[root] = ix[child]; ix[child] = ti;
     root = child; child = 2 * root + 1;
