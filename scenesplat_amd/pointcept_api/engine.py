@@ -450,18 +450,18 @@ class MultiDatasetLoader:
                 s.set_epoch(epoch)
 
     def __iter__(self):
-        its = [iter(dl) for dl in self.dataloaders]
-        while True:
-            for i, r in enumerate(self.ratios):
-                for _ in range(r):
-                    try:
-                        batch = next(its[i])
-                    except StopIteration:
-                        if i == 0:
-                            return
-                        its[i] = iter(self.dataloaders[i])
-                        batch = next(its[i])
-                    yield batch
+        import itertools
+        slots = [i for i, r in enumerate(self.ratios) for _ in range(r)]      # one round: r_i consecutive slots for loader i
+        streams = [iter(dl) for dl in self.dataloaders]
+        done = object()
+        for i in itertools.cycle(slots):
+            batch = next(streams[i], done)
+            if batch is done:
+                if i == 0:                       # the main dataset defines the epoch
+                    return
+                streams[i] = iter(self.dataloaders[i])    # the others start over
+                batch = next(streams[i])
+            yield batch
 
     def __len__(self):
         full, rem = divmod(len(self.dataloaders[0]), self.ratios[0])
