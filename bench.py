@@ -595,6 +595,13 @@ def main():
     steady = SteadyStateStep(fwd_bwd, list(model.parameters()), warmup=1, enabled=use_graph,
                              tail=fwd_bwd_tail if split else None, between=(lambda: exchange.reduce_begin("early")) if split else None)
 
+    if os.environ.get("SS_BENCH_INJECT_CAPTURE_INVALIDATED") == "1" and os.environ.get("SS_BENCH_CHILD") != "1":
+        # TEST HOOK (tests/test_hip_bench_paths.py): the first capture attempt reports an invalidated capture without touching the
+        # stream, so that the handler below -- fresh child process with eager launches, its JSON line forwarded -- is exercised
+        def _injected(plan_, inputs_):
+            raise CaptureInvalidated("injected by SS_BENCH_INJECT_CAPTURE_INVALIDATED")
+        steady._capture = _injected
+
     seg = {"zero": 0.0, "steady": 0.0, "reduce": 0.0, "plan": 0.0} if os.environ.get("SS_BENCH_HOST_SEGMENTS") else None
 
     def step():
