@@ -172,6 +172,9 @@ int ss_linear_fwd(const void* x, const void* weight, const float* bias, void* ou
  * ss_subm_conv_wgrad_pipe: contract of ss_subm_conv_wgrad (which dispatches to it for wide, large levels).
  * ss_linear_wgrad: dweight (n_out,k_in) f32 += dy (m,n_out)^T @ x (m,k_in), both bf16 -- the nn.Linear weight gradient;
  * dbias (n_out) f32, ZERO on entry, += column sums of dy (the bias gradient), or NULL. */
+/* 1: the weight-gradient kernels order their output tiles XCD-aware (runs of 3 tiles that stream the same rows go to one XCD) */
+int ss_wgrad_xcd_order(void);
+int ss_wgrad_set_xcd_order(int on);   /* tuning knob (default: off; environment SS_WGRAD_XCD_TRIPLE=1 turns it on) */
 int ss_wgrad8_ok(int64_t n, int cin, int cout, int taps);
 int ss_subm_conv_wgrad_pipe(const void* in, const void* dout, const int32_t* nbr, const int32_t* rowperm,
                             const int32_t* blk_count, const int32_t* blk_list, float* dweight, int64_t n, int cin, int cout,

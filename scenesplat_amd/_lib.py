@@ -62,6 +62,8 @@ PROTOTYPES = {
     "ss_gemm8_ok": (c_i, [c_i64, c_i, c_i, c_i]),
     "ss_subm_conv_fwd_pipe": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "ss_linear_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
+    "ss_wgrad_xcd_order": (c_i, []),
+    "ss_wgrad_set_xcd_order": (c_i, [c_i]),
     "ss_wgrad8_ok": (c_i, [c_i64, c_i, c_i, c_i]),
     "ss_subm_conv_wgrad_pipe": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "ss_linear_wgrad": (c_i, [c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_p]),

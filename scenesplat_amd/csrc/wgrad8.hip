@@ -318,14 +318,30 @@ w8_body(const unsigned short* __restrict__ X, const unsigned short* __restrict__
 
 #undef W8_BIAS
 
+// XCD-aware order of the output tiles (round 4).  Workgroup id i is dispatched to XCD i % 8.  Tiles that are consecutive in L (Cin-tile
+// fastest) stream the SAME dy rows; dealt round-robin over the XCDs (rounds 1-3) every one of them fetches those rows through its own
+// L2.  Here runs of W8_XG = 3 consecutive tiles go to ONE XCD in consecutive slots, the runs round-robin over the XCDs: measured on
+// the dec0 conv weight gradient 1.077 -> 1.041 ms stand-alone, but +0.25 ms on the whole step (see ss_wgrad_xcd_order: off by default;
+// all NINE tiles of a (tap, share) on one XCD was 20-45 % slower, round 1).  `first` = the id of the problem's first workgroup (a multiple of 8), nb = its workgroup count.
+#define W8_XG 3
+__device__ __forceinline__ int w8_xcd_order(int L, int nb) {
+  const int row = 8 * W8_XG, full = nb / row * row;
+  if (L >= full) return L;
+  const int xcd = L & 7, slot = L >> 3;
+  return ((slot / W8_XG) * 8 + xcd) * W8_XG + slot % W8_XG;
+}
+
 template <bool GATHER>
 __global__ void __launch_bounds__(512)
 k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict__ DY, const int32_t* __restrict__ nbr,
          const int32_t* __restrict__ rowperm, const int32_t* __restrict__ blk_count, const int32_t* __restrict__ blk_list,
          float* __restrict__ dW, float* __restrict__ dbias, int n, int Cin, int Cout, int taps, int ntn, int nblocks_total,
          int min_per, int ntiles, int nshares, int walk) {
+  // walk bit 1: XCD-aware tile order (w8_xcd_order; SS_WGRAD_XCD_TRIPLE=0 restores the round-robin order)
+  int L = (int)blockIdx.x;
+  if (walk & 2) L = w8_xcd_order(L, (int)gridDim.x);
   w8_body<GATHER>(X, DY, nbr, rowperm, blk_count, blk_list, dW, dbias, n, Cin, Cout, taps, ntn, nblocks_total, min_per, ntiles,
-                  nshares, (int)blockIdx.x, walk);
+                  nshares, L, walk & 1);
 }
 
 // Grouped nn.Linear weight gradients: ONE launch for many independent problems (the six identical blocks of a pooled
@@ -333,7 +349,7 @@ k_wgrad8(const unsigned short* __restrict__ X, const unsigned short* __restrict_
 // per problem = {x, dy, dW, dbias, m, k_in | n_out << 32, ntn | ntiles << 32, nshares | min_per << 32}; wg_start
 // (nprob + 1): first workgroup of every problem.
 __global__ void __launch_bounds__(512)
-k_wgrad8_group(const int64_t* __restrict__ desc, const int32_t* __restrict__ wg_start, int nprob) {
+k_wgrad8_group(const int64_t* __restrict__ desc, const int32_t* __restrict__ wg_start, int nprob, int nprob_flags) {
   const int b = blockIdx.x;
   int p = 0;
   while (p + 1 < nprob && wg_start[p + 1] <= b) ++p;          // nprob <= 128: a scalar scan
@@ -343,9 +359,27 @@ k_wgrad8_group(const int64_t* __restrict__ desc, const int32_t* __restrict__ wg_
   const int k_in = (int)(w5 & 0xffffffffu), n_out = (int)(w5 >> 32);
   const int ntn = (int)(w6 & 0xffffffffu), ntiles = (int)(w6 >> 32);
   const int nshares = (int)(w7 & 0xffffffffu), min_per = (int)(w7 >> 32);
+  // XCD-aware tile order inside the problem: the workgroups before the first id that is a multiple of 8 keep their place, the rest is
+  // ordered as if the problem started there (no padding workgroups: a launch is planned as ONE round of <= 256 workgroups, and ids that
+  // leave at once would skew the XCDs' shares of the real ones -- measured +2.6 ms per step with padded problems)
+  int L = b - wg_start[p];
+  if (nprob_flags & 1) {
+    const int a = (8 - (wg_start[p] & 7)) & 7;
+    if (L >= a) L = a + w8_xcd_order(L - a, nshares * ntiles - a);
+  }
   w8_body<false>((const unsigned short*)d[0], (const unsigned short*)d[1], nullptr, nullptr, nullptr, nullptr, (float*)d[2],
-                 (float*)d[3], (int)m, k_in, n_out, 1, ntn, (int)((m + 63) / 64), min_per, ntiles, nshares, b - wg_start[p]);
+                 (float*)d[3], (int)m, k_in, n_out, 1, ntn, (int)((m + 63) / 64), min_per, ntiles, nshares, L);
 }
+
+// XCD-aware tile order of the conv weight gradient: default OFF.  Stand-alone it wins (dec0 1.077 -> 1.041 ms, dec1 188 -> 184 us, two
+// repetitions), inside the step it loses (in-process interleaved A/B, scripts/ab_step.py wgrad_xcd: 37.48 ms with, 37.23 without).
+static int w8_xcd_flag = -1;
+extern "C" int ss_wgrad_xcd_order(void) {
+  if (w8_xcd_flag < 0) { const char* e = getenv("SS_WGRAD_XCD_TRIPLE"); w8_xcd_flag = (e && atoi(e) == 1) ? 1 : 0; }
+  return w8_xcd_flag;
+}
+// A/B switch of scripts/ab_step.py (a process-wide tuning knob, like the environment variable it overrides)
+extern "C" int ss_wgrad_set_xcd_order(int on) { w8_xcd_flag = on ? 1 : 0; return SS_OK; }
 
 extern "C" int ss_wgrad8_ok(int64_t n, int cin, int cout, int taps) {
   return n > 0 && n < (1LL << 31) && cin >= 8 && (cin & 7) == 0 && cin <= W8_ZERO_ELEMS && cout >= 8 && (cout & 7) == 0 &&
@@ -388,6 +422,7 @@ static int w8_conv_launch(const void* in, const void* dout, const int32_t* nbr, 
   if (env_per == -2) { const char* e = getenv("SS_WGRAD_MINPER"); env_per = e ? atoi(e) : -1; }
   int min_per = env_per > 0 ? env_per : w8_min_per((int64_t)tm * tn * ((taps + 2) / 3), (int64_t)nblocks * 7 / 10);
   int splits = ss_div_up(nblocks, min_per);
+  if (ss_wgrad_xcd_order()) walk |= 2;
   dim3 g((unsigned)((int64_t)taps * splits * tm * tn));
   SS_LAUNCH((k_wgrad8<true>), g, dim3(512), 0, stream, (const unsigned short*)in, (const unsigned short*)dout, nbr, rowperm,
             blk_count, blk_list, dweight, (float*)nullptr, (int)n, cin, cout, taps, tn, nblocks, min_per, tm * tn, splits, walk);
@@ -442,7 +477,9 @@ extern "C" int ss_linear_wgrad_group(const int64_t* desc, const int32_t* wg_star
                                      hipStream_t stream) {
   if (nprob <= 0 || total_workgroups <= 0) return SS_OK;
   if (!desc || !wg_start || nprob > 128) return SS_ERR_ARG;
-  SS_LAUNCH(k_wgrad8_group, dim3((unsigned)total_workgroups), dim3(512), 0, stream, desc, wg_start, nprob);
+  // (the XCD-aware order is NOT applied to the Linear problems: in-process A/B of the whole step 36.79 ms with it, 36.58 without -- their
+  // launches are ONE round of <= 256 workgroups, every tile of a run would be resident at once on neighbouring CUs of one XCD)
+  SS_LAUNCH(k_wgrad8_group, dim3((unsigned)total_workgroups), dim3(512), 0, stream, desc, wg_start, nprob, 0);
   return SS_OK;
 }
 

@@ -56,6 +56,8 @@ def setter(on):
         SF.CONV_WALK_RULEBOOK = on
     elif which == "gelu":
         SF.GELU_HIP = on
+    elif which == "wgrad_xcd":        # XCD-aware tile order of the weight-gradient kernels (wgrad8.hip: w8_xcd_order)
+        nv.lib().ss_wgrad_set_xcd_order(1 if on else 0)
     elif which == "hm_rows":          # the qkv projection's head-major epilogue also on levels of 1,024 .. 4,095 rows (enc3: 1,600)
         SF.HM_FUSED_MIN_ROWS = 1024 if on else 4096
     elif which == "hm_ch":            # ... and from 64 channels on (enc1: 25,600 x 64)
