@@ -98,3 +98,18 @@ def test_plan_ahead_bounds_its_retries_and_waits_at_the_sync_gate(monkeypatch):
         assert built == []                                        # parked at the gate
     assert ahead.get() == "plan"
     ahead.close()
+
+
+def test_multi_dataset_loader_follows_the_reference_schedule():
+    """MultiDatasetLoader = the batch schedule of pointcept/datasets/dataloader.py:23-102: ratios[i] consecutive batches from loader i per
+    round, the FIRST loader ends the epoch, the others start over; len() as dataloader.py:97-102."""
+    from scenesplat_amd.pointcept_api.engine import MultiDatasetLoader
+    l = MultiDatasetLoader([list("abcde"), list("XY"), list("12345678")], [2, 1, 3])
+    assert "".join(l) == "abX123cdY456e" and len(l) == 13 == 5 // 2 * 6 + 5 % 2
+    assert "".join(l) == "abX123cdY456e"                        # a second epoch starts every loader afresh
+    one = MultiDatasetLoader([list("ab")], [3])
+    assert "".join(one) == "ab" and len(one) == 2
+    exact = MultiDatasetLoader([list("abcd"), list("X")], [2, 2])
+    assert "".join(exact) == "abXXcdXX" and len(exact) == 8     # the main loader runs out exactly at a round's end: the round completes
+    with pytest.raises(ValueError):
+        MultiDatasetLoader([list("ab")], [0])
